@@ -1,0 +1,153 @@
+"""Independent NumPy restatement of the reference hot path -- the oracle's cross-check.
+
+TEST INFRASTRUCTURE (same rules as oracle/pigo_oracle.c: tests / smoke / cpu_baseline only).
+
+Written separately from the C oracle and in a different shape (vectorised over all windows of one
+scale, tree by tree) so that a transcription slip in either restatement shows up as a diff:
+
+    Unpack                 /root/reference/core/pigo.go:51-110
+    classifyRegion         /root/reference/core/pigo.go:113-147
+    classifyRotatedRegion  /root/reference/core/pigo.go:150-191
+    RunCascade             /root/reference/core/pigo.go:212-258
+    ClusterDetections      /root/reference/core/pigo.go:262-308   (stable tie order -- see below)
+
+float32 leaf accumulation is done with numpy float32 arrays (one IEEE add per tree, sequential in
+tree order), the ladder in Python floats (IEEE double), the IoU in Python floats.
+
+Tie rule: ``cluster_detections`` here sorts STABLY by Q.  Go's sort.Slice is unstable for n > 12, so
+this function agrees with the C oracle (which restates Go's pdqsort) only on tie-free inputs or
+n <= 12; tests use it exactly that way.
+"""
+import struct
+
+import numpy as np
+
+Q_COS = [256, 251, 236, 212, 181, 142, 97, 49, 0, -49, -97, -142, -181, -212, -236, -251, -256, -251, -236, -212, -181, -142,
+         -97, -49, 0, 49, 97, 142, 181, 212, 236, 251, 256]  # pigo.go:156
+Q_SIN = [0, 49, 97, 142, 181, 212, 236, 251, 256, 251, 236, 212, 181, 142, 97, 49, 0, -49, -97, -142, -181, -212, -236, -251,
+         -256, -251, -236, -212, -181, -142, -97, -49, 0]  # pigo.go:157
+
+
+class NpPigo:
+    def __init__(self, codes, preds, thr, depth):
+        self.codes = codes  # int8 [ntrees, 4*2^depth] (4 leading zero bytes per tree, pigo.go:79)
+        self.preds = preds  # float32 [ntrees, 2^depth]
+        self.thr = thr  # float32 [ntrees]
+        self.depth = depth
+        self.ntrees = len(thr)
+
+    @classmethod
+    def unpack(cls, packet: bytes):
+        depth, ntrees = struct.unpack_from("<II", packet, 8)  # pigo.go:61-68
+        nleaf = 1 << depth
+        ncode = 4 * nleaf - 4
+        rec = ncode + 4 * nleaf + 4
+        if len(packet) < 16 + ntrees * rec:
+            raise IndexError("packet too short")
+        body = np.frombuffer(packet, dtype=np.uint8, count=ntrees * rec, offset=16).reshape(ntrees, rec)
+        codes = np.zeros((ntrees, 4 * nleaf), dtype=np.int8)
+        codes[:, 4:] = body[:, :ncode].view(np.int8)
+        preds = np.ascontiguousarray(body[:, ncode:ncode + 4 * nleaf]).view("<f4").reshape(ntrees, nleaf)
+        thr = np.ascontiguousarray(body[:, ncode + 4 * nleaf:]).view("<f4").reshape(ntrees)
+        return cls(codes, preds.copy(), thr.copy(), depth)
+
+    # one scale, all windows at once ---------------------------------------------------------------
+    def _scan_scale(self, pix, npix, rows, cols, dim, s, step, angle):
+        off = s // 2 + 1 if s >= 0 else -((-s) // 2) + 1  # Go int division truncates toward zero
+        rr = np.arange(off, rows - off + 1, step, dtype=np.int64)
+        cc = np.arange(off, cols - off + 1, step, dtype=np.int64)
+        if len(rr) == 0 or len(cc) == 0:
+            return np.zeros((0, 4)), 0
+        R, Cc = np.meshgrid(rr, cc, indexing="ij")
+        R = R.ravel()
+        Cc = Cc.ravel()
+        nwin = R.size
+        alive = np.arange(nwin)
+        out = np.zeros(nwin, dtype=np.float32)
+        nleaf = 1 << self.depth
+        rotated = angle > 0.0
+        if rotated:
+            k = int(32.0 * min(angle, 1.0))
+            qsin, qcos = s * Q_SIN[k], s * Q_COS[k]
+        for t in range(self.ntrees):
+            if alive.size == 0:
+                break
+            r, c = R[alive], Cc[alive]
+            idx = np.ones(alive.size, dtype=np.int64)
+            tc = self.codes[t].astype(np.int64)
+            for _ in range(self.depth):
+                c0, c1, c2, c3 = tc[4 * idx], tc[4 * idx + 1], tc[4 * idx + 2], tc[4 * idx + 3]
+                if not rotated:
+                    x1 = ((r * 256 + c0 * s) >> 8) * dim + ((c * 256 + c1 * s) >> 8)
+                    x2 = ((r * 256 + c2 * s) >> 8) * dim + ((c * 256 + c3 * s) >> 8)
+                else:
+                    lim = rows - 1  # quirk Q1: nrows-1 clamps the columns too (pigo.go:168,171)
+                    r1 = np.minimum(lim, np.maximum(0, 65536 * r + qcos * c0 - qsin * c1) >> 16)
+                    k1 = np.minimum(lim, np.maximum(0, 65536 * c + qsin * c0 + qcos * c1) >> 16)
+                    r2 = np.minimum(lim, np.maximum(0, 65536 * r + qcos * c2 - qsin * c3) >> 16)
+                    k2 = np.minimum(lim, np.maximum(0, 65536 * c + qsin * c2 + qcos * c3) >> 16)
+                    x1 = np.abs(r1) * dim + np.abs(k1)
+                    x2 = np.abs(r2) * dim + np.abs(k2)
+                if x1.min() < 0 or x2.min() < 0 or x1.max() >= npix or x2.max() >= npix:
+                    raise IndexError("pixel index out of range (Go would panic)")
+                idx = 2 * idx + (pix[x1] <= pix[x2])
+            o = out[alive] + self.preds[t][idx - nleaf]  # float32 + float32
+            keep = o > self.thr[t]  # reject when out <= thr (pigo.go:139)
+            out[alive] = o
+            alive = alive[keep]
+        if self.ntrees == 0:
+            return np.zeros((0, 4)), nwin
+        q = out[alive] - self.thr[self.ntrees - 1]
+        pos = q > 0
+        alive, q = alive[pos], q[pos]
+        res = np.stack([R[alive], Cc[alive], np.full(alive.size, s), q.astype(np.float64)], axis=1)
+        return res, nwin
+
+    def run_cascade(self, pixels, rows, cols, dim, min_size, max_size, shift, scale_factor, angle=0.0):
+        pix = np.ascontiguousarray(pixels, dtype=np.uint8).ravel()
+        dets, nwin = [], 0
+        s = int(min_size)
+        while s <= max_size:
+            step = int(max(shift * float(s), 1.0))
+            d, n = self._scan_scale(pix, pix.size, rows, cols, dim, s, step, angle)
+            nwin += n
+            if len(d):
+                dets.append(d)
+            s = int(float(s) + max(2.0, float(s) * scale_factor - float(s)))
+        if dets:
+            d = np.concatenate(dets, axis=0)
+        else:
+            d = np.zeros((0, 4))
+        return d, nwin
+
+    @staticmethod
+    def calc_iou(d1, d2):
+        r1, c1, s1 = float(d1[0]), float(d1[1]), float(d1[2])
+        r2, c2, s2 = float(d2[0]), float(d2[1]), float(d2[2])
+        over_r = max(0.0, min(r1 + s1 / 2, r2 + s2 / 2) - max(r1 - s1 / 2, r2 - s2 / 2))
+        over_c = max(0.0, min(c1 + s1 / 2, c2 + s2 / 2) - max(c1 - s1 / 2, c2 - s2 / 2))
+        return over_r * over_c / (s1 * s1 + s2 * s2 - over_r * over_c)
+
+    @classmethod
+    def cluster_detections(cls, dets, iou_threshold):
+        """dets: list of (row, col, scale, q[float32-valued]); STABLE sort by q (see module docstring)."""
+        d = sorted([(int(a), int(b), int(c), np.float32(q)) for a, b, c, q in dets], key=lambda t: t[3])
+        n = len(d)
+        assigned = [False] * n
+        clusters = []
+        for i in range(n):
+            if assigned[i]:
+                continue
+            r = c = s = cnt = 0
+            q = np.float32(0.0)
+            for j in range(n):
+                if cls.calc_iou(d[i], d[j]) > iou_threshold:
+                    assigned[j] = True
+                    r += d[j][0]
+                    c += d[j][1]
+                    s += d[j][2]
+                    q = np.float32(q + d[j][3])
+                    cnt += 1
+            if cnt > 0:
+                clusters.append((r // cnt, c // cnt, s // cnt, q))
+        return d, clusters
