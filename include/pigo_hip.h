@@ -1,0 +1,156 @@
+/*
+ * pigo_hip.h -- C ABI of libpigo_hip.so: the MI355X (gfx950) implementation of Pigo's cascade scan.
+ *
+ * This is the drop-in boundary.  The reference (esimov/pigo, pure Go) has no FFI seam on this path;
+ * the seam is the exported Go API of package github.com/esimov/pigo/core, so every entry point below
+ * names the Go method it stands in for (file:line under /root/reference).  INTEGRATION.md shows the
+ * cgo shim a maintainer adds on the Go side; include/pigo.hpp is the C++ mirror of the same API and
+ * pigo_amd/core.py the ctypes one.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in the signatures (a stream is passed as void*).
+ *   - every function returns a pigo_status (0 = ok, < 0 = error) and never aborts the process.
+ *     The reference has no error channel on this path: where the Go code would panic (short packet,
+ *     pixel index out of range) the C ABI returns PIGO_ERR_PACKET / PIGO_ERR_PANIC and the shim
+ *     re-raises it as a Go panic.
+ *   - host buffers passed in (packet, pixels, dets) are only read/written during the call and never
+ *     retained (cgo pointer rules).
+ *   - a handle may be used from any OS thread; calls on one handle are serialised internally.
+ *   - the library is GPU-only: there is no CPU fallback.  Without a usable gfx950 device every
+ *     entry point that needs one fails with PIGO_ERR_HIP.
+ */
+#ifndef PIGO_HIP_H
+#define PIGO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int pigo_status;
+#define PIGO_OK 0
+#define PIGO_ERR_PACKET (-1)   /* Unpack: packet shorter than its header says (Go: slice panic, pigo.go:64,81,90) */
+#define PIGO_ERR_PARAM (-2)    /* argument outside what the library supports (see each function) */
+#define PIGO_ERR_HIP (-3)      /* HIP runtime error / no device; pigo_last_error() has the text */
+#define PIGO_ERR_CAPACITY (-4) /* output buffer too small; *n_out holds the required element count */
+#define PIGO_ERR_PANIC (-5)    /* the reference would panic: pixel index out of range (rotated scan, quirk Q1) */
+#define PIGO_ERR_NOMEM (-6)
+
+/* Detection, core/pigo.go:195-200.  16-byte wire/GPU record; the Go shim widens it to Go's
+ * {Row, Col, Scale int; Q float32}. */
+typedef struct {
+    int32_t row, col, scale;
+    float q;
+} pigo_det;
+
+/* type Pigo (core/pigo.go:37-43): the unpacked cascade, plus its device-resident tables. */
+typedef struct pigo_cascade pigo_cascade;
+
+/* A scan plan: CascadeParams (core/pigo.go:16-34) minus the pixels, bound to a cascade, with the
+ * per-scale offset tables, the window/tile index space and the device workspace for a batch. */
+typedef struct pigo_plan pigo_plan;
+
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char *pigo_last_error(void);
+
+/* Number of visible HIP devices (0 if none / no driver). */
+int pigo_device_count(void);
+
+/* ---- (*Pigo).Unpack, core/pigo.go:51-110 ------------------------------------------------------
+ * Parses the cascade file, uploads the tables to `device` and returns a new handle.  Like the
+ * reference it accepts any tree depth / tree count the header states (depth <= 12 here).
+ * PIGO_ERR_PACKET when the reference would panic on a short packet. */
+pigo_status pigo_cascade_create(const uint8_t *packet, size_t len, int device, pigo_cascade **out);
+pigo_status pigo_cascade_info(const pigo_cascade *c, uint32_t *tree_depth, uint32_t *tree_num);
+/* copies of the unpacked tables (treeCodes / treePred / treeThreshold, pigo.go:38-40); any pointer may be NULL */
+pigo_status pigo_cascade_tables(const pigo_cascade *c, int8_t *codes, size_t ncodes, float *pred, size_t npred, float *thr,
+                                size_t nthr);
+void pigo_cascade_destroy(pigo_cascade *c);
+
+/* ---- (*Pigo).RunCascade, core/pigo.go:212-258 ---------------------------------------------------
+ * One frame, host memory in, host memory out.  `pixels` = ImageParams.Pixels (row-major gray,
+ * stride `dim`), npixels = len(Pixels).  Detections (q > 0 only) are written in the reference's
+ * order: scale-major, then row, then col.  angle > 0 takes the classifyRotatedRegion path (angle is
+ * clamped to 1.0 like pigo.go:233-235); angle <= 0 the classifyRegion path.
+ * Returns PIGO_ERR_CAPACITY (and the needed count in *n_out) if more than `cap` detections exist.
+ * Deviations from the reference, all reported as PIGO_ERR_PARAM instead of Go's undefined/panicking
+ * behaviour: min_size < 0, dim < cols, npixels < rows*dim, rows/cols/dim >= 65536, non-finite
+ * shift/scale factors, more than 2^32-1 windows or more than 2047 non-empty scales. */
+pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, size_t npixels, int rows, int cols, int dim, int min_size,
+                             int max_size, double shift_factor, double scale_factor, double angle, pigo_det *out, int cap,
+                             int *n_out);
+
+/* ---- (*Pigo).ClusterDetections, core/pigo.go:262-308 ---------------------------------------------
+ * Sorts `dets` in place by ascending Q exactly like the reference's sort.Slice (Go's pdqsort,
+ * restated host-side), then runs the IoU clustering on the GPU.  `out` needs room for up to n
+ * clusters.  n <= 65536. */
+pigo_status pigo_cluster_detections(pigo_cascade *c, pigo_det *dets, int n, double iou_threshold, pigo_det *out, int cap,
+                                    int *n_out);
+/* The sort step alone (host): sort.Slice(dets, func(i, j) bool { return dets[i].Q < dets[j].Q }), pigo.go:264 */
+void pigo_sort_by_q(pigo_det *dets, int n);
+
+/* ---- batch / device-resident extension (BASELINE configs 2-5; no reference counterpart) ----------
+ * A plan fixes (rows, cols, dim, MinSize, MaxSize, ShiftFactor, ScaleFactor, angle) and owns the
+ * workspace for up to `max_frames` frames with up to `det_cap` raw detections per frame. */
+pigo_status pigo_plan_create(pigo_cascade *c, int rows, int cols, int dim, int min_size, int max_size, double shift_factor,
+                             double scale_factor, double angle, int max_frames, int det_cap, pigo_plan **out);
+void pigo_plan_destroy(pigo_plan *p);
+
+typedef struct {
+    int64_t windows_per_frame; /* every (scale,row,col) RunCascade would classify */
+    int32_t n_scales;          /* non-empty rungs of the scale ladder */
+    int32_t n_ladder;          /* all rungs, including the ones larger than the image */
+    int32_t tiles_per_frame;   /* workgroups per frame of the head kernel */
+    int32_t n_head_trees;      /* trees evaluated by the dense head kernel */
+    int32_t variant;           /* 0 = monolithic scan, 1 = head + compacted tail */
+    int32_t max_frames, det_cap;
+    int64_t queue_capacity;    /* survivor-queue entries shared by the batch */
+    int64_t workspace_bytes;
+} pigo_plan_info_t;
+pigo_status pigo_plan_info(const pigo_plan *p, pigo_plan_info_t *info);
+
+/* Selects the scan implementation for this plan: 0 = monolithic lane-per-window kernel (also the
+ * overflow fallback), 1 = dense head + compacted tail (default when the cascade has depth 6). */
+pigo_status pigo_plan_set_variant(pigo_plan *p, int variant);
+
+/* Asynchronous scan of `nframes` (<= max_frames) device-resident frames.  `d_frames` points to
+ * nframes consecutive frames of `frame_stride` bytes each (>= rows*dim) in device memory.
+ * Enqueues on `stream` (a hipStream_t, NULL = default stream):
+ *     d_dets   [nframes][det_cap] pigo_det, reference order per frame
+ *     d_counts [nframes] int32: detections found (if > det_cap the frame's list is truncated)
+ * Nothing is synchronised; call pigo_plan_status() after synchronising the stream. */
+pigo_status pigo_plan_run(pigo_plan *p, const uint8_t *d_frames, size_t frame_stride, int nframes, pigo_det *d_dets,
+                          int32_t *d_counts, void *stream);
+
+/* Asynchronous per-frame ClusterDetections of the lists produced by pigo_plan_run (same stream):
+ * sorts each frame's list by (Q ascending, reference index) -- a STABLE order, which equals Go's
+ * sort.Slice whenever a frame has no tied Q values; d_ties[f] (may be NULL) receives the number of
+ * adjacent equal-Q pairs so callers can detect the unpinned case -- then clusters on the GPU.
+ *     d_sorted   [nframes][det_cap] the frame's detections, sorted (what the reference leaves in the caller's slice)
+ *     d_clusters [nframes][det_cap], d_ccounts [nframes] */
+pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, const int32_t *d_counts, int nframes, double iou_threshold,
+                              pigo_det *d_sorted, pigo_det *d_clusters, int32_t *d_ccounts, int32_t *d_ties, void *stream);
+
+/* After the stream has been synchronised: PIGO_OK, PIGO_ERR_PANIC (the reference would have
+ * panicked on some frame) or PIGO_ERR_CAPACITY (survivor queue overflowed: results of the last run
+ * are incomplete; pigo_plan_run_sync handles this by re-running with the monolithic kernel). */
+pigo_status pigo_plan_status(pigo_plan *p);
+
+/* Synchronous convenience wrapper: run + synchronise + overflow fallback. */
+pigo_status pigo_plan_run_sync(pigo_plan *p, const uint8_t *d_frames, size_t frame_stride, int nframes, pigo_det *d_dets,
+                               int32_t *d_counts, void *stream);
+
+/* Per-kernel timing of the most recent pigo_plan_run when profiling is on (HIP events recorded on
+ * the run's stream around each kernel).  names/ms arrays of length `cap`; returns the kernel count. */
+pigo_status pigo_plan_set_profiling(pigo_plan *p, int on);
+int pigo_plan_last_timings(pigo_plan *p, const char **names, float *ms, int cap);
+
+/* Device statistics of the most recent run (valid after synchronising): survivor-queue entries. */
+pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIGO_HIP_H */

@@ -1,0 +1,124 @@
+"""Device-resident batch scan: the extension of RunCascade that BASELINE configs 2-5 measure.
+
+A ``ScanPlan`` fixes CascadeParams (minus the pixels) and owns the GPU workspace for a batch of frames
+that already live in HBM.  PyTorch is used only as plumbing here -- device memory (uint8 / int32 tensors
+whose ``data_ptr()`` is handed to the C ABI), the current HIP stream and ``torch.distributed`` -- all the
+work happens in libpigo_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import core
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class ScanPlan:
+    """pigo_plan (include/pigo_hip.h): CascadeParams bound to a cascade + workspace for `max_frames`."""
+
+    def __init__(self, pigo: "core.Pigo", rows, cols, dim=None, MinSize=20, MaxSize=1000, ShiftFactor=0.1, ScaleFactor=1.1,
+                 angle=0.0, max_frames=1, det_cap=4096):
+        self.L = core.load_library()
+        self.pigo = pigo
+        self.rows, self.cols, self.dim = int(rows), int(cols), int(dim if dim is not None else cols)
+        self.max_frames, self.det_cap = int(max_frames), int(det_cap)
+        h = C.c_void_p()
+        core.check(self.L.pigo_plan_create(pigo._need(), self.rows, self.cols, self.dim, int(MinSize), int(MaxSize), float(ShiftFactor),
+                                           float(ScaleFactor), float(angle), self.max_frames, self.det_cap, C.byref(h)), "plan_create")
+        self._h = h
+        self.device = pigo.device
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and core._lib is not None:
+            core._lib.pigo_plan_destroy(h)
+
+    def info(self) -> core.PlanInfo:
+        inf = core.PlanInfo()
+        core.check(self.L.pigo_plan_info(self._h, C.byref(inf)))
+        return inf
+
+    def set_variant(self, variant: int):
+        core.check(self.L.pigo_plan_set_variant(self._h, int(variant)), "set_variant")
+
+    def set_profiling(self, on: bool):
+        core.check(self.L.pigo_plan_set_profiling(self._h, 1 if on else 0))
+
+    # -- buffers ---------------------------------------------------------------------------------------------
+    def alloc_outputs(self, nframes=None):
+        """(dets uint8-viewed-as-records [n, det_cap, 16 B], counts int32 [n]) on the plan's device."""
+        torch = _torch()
+        n = self.max_frames if nframes is None else nframes
+        dev = torch.device("cuda", self.device)
+        dets = torch.zeros((n, self.det_cap, 4), dtype=torch.int32, device=dev)
+        counts = torch.zeros((n,), dtype=torch.int32, device=dev)
+        return dets, counts
+
+    @staticmethod
+    def _stream_ptr(stream):
+        torch = _torch()
+        s = torch.cuda.current_stream() if stream is None else stream
+        return C.c_void_p(s.cuda_stream)
+
+    def _check_frames(self, frames):
+        torch = _torch()
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.is_contiguous()
+        assert frames.dim() == 3 and frames.shape[1] == self.rows and frames.shape[2] == self.dim, frames.shape
+        assert frames.shape[0] <= self.max_frames
+        return int(frames.shape[0]), self.rows * self.dim
+
+    # -- RunCascade over a batch --------------------------------------------------------------------------------
+    def run(self, frames, dets, counts, stream=None, sync=False):
+        """Enqueue the scan of ``frames`` (uint8 [n, rows, dim], device) on the current stream.
+
+        dets: int32 [n, det_cap, 4] (row, col, scale, q-bits) in the reference's order; counts: int32 [n]."""
+        n, stride = self._check_frames(frames)
+        fn = self.L.pigo_plan_run_sync if sync else self.L.pigo_plan_run
+        core.check(fn(self._h, C.c_void_p(frames.data_ptr()), stride, n, C.c_void_p(dets.data_ptr()), C.c_void_p(counts.data_ptr()),
+                      self._stream_ptr(stream)), "plan_run")
+
+    def status(self):
+        """Call after synchronising: raises PigoPanic / PigoError(capacity) like the single-frame API."""
+        core.check(self.L.pigo_plan_status(self._h), "plan_status")
+
+    def alloc_cluster_outputs(self, dets, counts):
+        torch = _torch()
+        return torch.zeros_like(dets), torch.zeros_like(dets), torch.zeros_like(counts), torch.zeros_like(counts)
+
+    def cluster(self, dets, counts, iou, stream=None, out=None):
+        """Per-frame ClusterDetections on the GPU.  Returns (sorted, clusters, ccounts, ties) tensors
+        (pass ``out=alloc_cluster_outputs(...)`` to reuse buffers)."""
+        n = int(counts.shape[0])
+        sorted_, clusters, ccounts, ties = out if out is not None else self.alloc_cluster_outputs(dets, counts)
+        core.check(self.L.pigo_plan_cluster(self._h, C.c_void_p(dets.data_ptr()), C.c_void_p(counts.data_ptr()), n, float(iou),
+                                            C.c_void_p(sorted_.data_ptr()), C.c_void_p(clusters.data_ptr()),
+                                            C.c_void_p(ccounts.data_ptr()), C.c_void_p(ties.data_ptr()), self._stream_ptr(stream)),
+                   "plan_cluster")
+        return sorted_, clusters, ccounts, ties
+
+    def last_timings(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        k = self.L.pigo_plan_last_timings(self._h, names, ms, 16)
+        return [(names[i].decode(), float(ms[i])) for i in range(k)]
+
+    def last_queue_count(self):
+        n = C.c_int64(0)
+        core.check(self.L.pigo_plan_last_queue_count(self._h, C.byref(n)))
+        return n.value
+
+
+def dets_to_numpy(dets, counts, frame=None):
+    """Device detection tensors -> list of Detection arrays (one per frame), truncated to det_cap."""
+    d = dets.cpu().numpy()
+    c = counts.cpu().numpy()
+    cap = d.shape[1]
+    out = []
+    for f in range(d.shape[0]):
+        n = min(int(c[f]), cap)
+        out.append(np.ascontiguousarray(d[f, :n]).view(core.DET_DTYPE).reshape(n).copy())
+    return out if frame is None else out[frame]

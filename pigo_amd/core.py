@@ -1,0 +1,231 @@
+"""Host-side mirror of the reference API (package github.com/esimov/pigo/core) over libpigo_hip.so.
+
+The Go toolchain is not available in this image, so the drop-in shim a Go maintainer would add is shown
+as source in INTEGRATION.md; this module is the same thin layer in Python (ctypes), with the reference's
+names, argument meaning and error behaviour, so that the parity tests read like core/pigo_test.go:
+
+    pg = Pigo().Unpack(cascade_bytes)                      # core/pigo.go:51
+    cp = CascadeParams(MinSize=20, MaxSize=1000, ShiftFactor=0.1, ScaleFactor=1.1,
+                       ImageParams=ImageParams(Pixels=gray, Rows=rows, Cols=cols, Dim=cols))
+    dets = pg.RunCascade(cp, 0.0)                          # core/pigo.go:212
+    dets = pg.ClusterDetections(dets, 0.2)                 # core/pigo.go:262
+
+There is NO CPU implementation behind these calls: every method goes through the C ABI into the HIP
+kernels and raises if the library or a GPU is missing.
+"""
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import build as _build
+
+#: Detection, core/pigo.go:195-200 -- the 16-byte wire record of the C ABI (pigo_det)
+DET_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("scale", "<i4"), ("q", "<f4")])
+
+PIGO_OK, ERR_PACKET, ERR_PARAM, ERR_HIP, ERR_CAPACITY, ERR_PANIC, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
+
+
+class PigoPanic(RuntimeError):
+    """The reference Go code would panic here (slice index out of range)."""
+
+
+class PigoError(RuntimeError):
+    pass
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("windows_per_frame", C.c_int64), ("n_scales", C.c_int32), ("n_ladder", C.c_int32), ("tiles_per_frame", C.c_int32),
+                ("n_head_trees", C.c_int32), ("variant", C.c_int32), ("max_frames", C.c_int32), ("det_cap", C.c_int32),
+                ("queue_capacity", C.c_int64), ("workspace_bytes", C.c_int64)]
+
+
+#: every symbol include/pigo_hip.h declares (tests check that the built library exports all of them)
+ABI_SYMBOLS = [
+    "pigo_last_error", "pigo_device_count", "pigo_cascade_create", "pigo_cascade_info", "pigo_cascade_tables", "pigo_cascade_destroy",
+    "pigo_run_cascade", "pigo_cluster_detections", "pigo_sort_by_q", "pigo_plan_create", "pigo_plan_destroy", "pigo_plan_info",
+    "pigo_plan_set_variant", "pigo_plan_run", "pigo_plan_cluster", "pigo_plan_status", "pigo_plan_run_sync", "pigo_plan_set_profiling",
+    "pigo_plan_last_timings", "pigo_plan_last_queue_count",
+]
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load_library():
+    """dlopen libpigo_hip.so (in-tree).  Fails loudly when it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise PigoError(f"{path} is missing: build it with `python -m pigo_amd.build` (hipcc, gfx950). "
+                        "pigo_amd has no CPU fallback.")
+    L = C.CDLL(path)
+    vp, i32, dbl, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+    L.pigo_last_error.restype = C.c_char_p
+    L.pigo_device_count.restype = i32
+    L.pigo_cascade_create.argtypes = [C.c_char_p, sz, i32, C.POINTER(vp)]
+    L.pigo_cascade_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.pigo_cascade_tables.argtypes = [vp, vp, sz, vp, sz, vp, sz]
+    L.pigo_cascade_destroy.argtypes = [vp]
+    L.pigo_cascade_destroy.restype = None
+    L.pigo_run_cascade.argtypes = [vp, vp, sz, i32, i32, i32, i32, i32, dbl, dbl, dbl, vp, i32, C.POINTER(i32)]
+    L.pigo_cluster_detections.argtypes = [vp, vp, i32, dbl, vp, i32, C.POINTER(i32)]
+    L.pigo_sort_by_q.argtypes = [vp, i32]
+    L.pigo_sort_by_q.restype = None
+    L.pigo_plan_create.argtypes = [vp, i32, i32, i32, i32, i32, dbl, dbl, dbl, i32, i32, C.POINTER(vp)]
+    L.pigo_plan_destroy.argtypes = [vp]
+    L.pigo_plan_destroy.restype = None
+    L.pigo_plan_info.argtypes = [vp, C.POINTER(PlanInfo)]
+    L.pigo_plan_set_variant.argtypes = [vp, i32]
+    L.pigo_plan_run.argtypes = [vp, vp, sz, i32, vp, vp, vp]
+    L.pigo_plan_run_sync.argtypes = [vp, vp, sz, i32, vp, vp, vp]
+    L.pigo_plan_cluster.argtypes = [vp, vp, vp, i32, dbl, vp, vp, vp, vp, vp]
+    L.pigo_plan_status.argtypes = [vp]
+    L.pigo_plan_set_profiling.argtypes = [vp, i32]
+    L.pigo_plan_last_timings.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), i32]
+    L.pigo_plan_last_queue_count.argtypes = [vp, C.POINTER(C.c_int64)]
+    for name in ABI_SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("pigo_device_count", "pigo_plan_last_timings"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(status, what=""):
+    if status == PIGO_OK:
+        return
+    msg = load_library().pigo_last_error().decode("utf-8", "replace")
+    text = f"{what}: {msg}" if what else msg
+    if status in (ERR_PACKET, ERR_PANIC):
+        raise PigoPanic(text)  # the Go shim re-raises these as panics, like the reference
+    if status == ERR_PARAM:
+        raise ValueError(text)
+    if status == ERR_NOMEM:
+        raise MemoryError(text)
+    raise PigoError(f"[{status}] {text}")
+
+
+# ---- the reference's parameter structs (core/pigo.go:16-34) ---------------------------------------------------
+
+
+@dataclass
+class ImageParams:
+    Pixels: np.ndarray = None  # row-major gray, stride Dim
+    Rows: int = 0
+    Cols: int = 0
+    Dim: int = 0
+
+
+@dataclass
+class CascadeParams:
+    MinSize: int = 0
+    MaxSize: int = 0
+    ShiftFactor: float = 0.0
+    ScaleFactor: float = 0.0
+    ImageParams: ImageParams = field(default_factory=ImageParams)
+
+
+def make_dets(rows):
+    """list of (row, col, scale, q) -> Detection array"""
+    a = np.zeros(len(rows), dtype=DET_DTYPE)
+    for i, r in enumerate(rows):
+        a[i] = tuple(r)
+    return a
+
+
+def sort_by_q(dets):
+    """sort.Slice(dets, func(i, j) bool { return dets[i].Q < dets[j].Q }) -- Go's pdqsort, in place."""
+    assert dets.dtype == DET_DTYPE and dets.flags.c_contiguous
+    load_library().pigo_sort_by_q(dets.ctypes.data, len(dets))
+    return dets
+
+
+class Pigo:
+    """type Pigo (core/pigo.go:37-43).  NewPigo() == Pigo()."""
+
+    def __init__(self, _handle=None, device=0):
+        self._h = _handle
+        self.device = device
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.pigo_cascade_destroy(h)
+
+    def close(self):
+        self.__del__()
+
+    # Unpack returns a NEW *Pigo and leaves the receiver untouched (core/pigo.go:51,103-109)
+    def Unpack(self, packet: bytes, device: int = None):
+        L = load_library()
+        dev = self.device if device is None else device
+        h = C.c_void_p()
+        check(L.pigo_cascade_create(bytes(packet), len(packet), dev, C.byref(h)), "Unpack")
+        return Pigo(h, dev)
+
+    def _need(self):
+        if not self._h:
+            raise PigoError("Pigo is not unpacked (call Unpack first)")
+        return self._h
+
+    @property
+    def treeDepth(self):
+        d, n = C.c_uint32(), C.c_uint32()
+        check(load_library().pigo_cascade_info(self._need(), C.byref(d), C.byref(n)))
+        return d.value
+
+    @property
+    def treeNum(self):
+        d, n = C.c_uint32(), C.c_uint32()
+        check(load_library().pigo_cascade_info(self._need(), C.byref(d), C.byref(n)))
+        return n.value
+
+    def tables(self):
+        """(treeCodes int8[ntrees, 4*2^d], treePred f32[ntrees, 2^d], treeThreshold f32[ntrees])"""
+        n, d = self.treeNum, self.treeDepth
+        codes = np.zeros((n, 4 << d), dtype=np.int8)
+        pred = np.zeros((n, 1 << d), dtype=np.float32)
+        thr = np.zeros(n, dtype=np.float32)
+        check(load_library().pigo_cascade_tables(self._need(), codes.ctypes.data, codes.size, pred.ctypes.data, pred.size,
+                                                 thr.ctypes.data, thr.size))
+        return codes, pred, thr
+
+    # RunCascade, core/pigo.go:212
+    def RunCascade(self, cp: CascadeParams, angle: float) -> np.ndarray:
+        ip = cp.ImageParams
+        pix = np.ascontiguousarray(ip.Pixels, dtype=np.uint8).ravel()
+        L = load_library()
+        cap = 1024
+        while True:
+            out = np.zeros(cap, dtype=DET_DTYPE)
+            n = C.c_int(0)
+            st = L.pigo_run_cascade(self._need(), pix.ctypes.data, pix.size, int(ip.Rows), int(ip.Cols), int(ip.Dim), int(cp.MinSize),
+                                    int(cp.MaxSize), float(cp.ShiftFactor), float(cp.ScaleFactor), float(angle), out.ctypes.data, cap,
+                                    C.byref(n))
+            if st == ERR_CAPACITY and n.value > cap:
+                cap = n.value
+                continue
+            check(st, "RunCascade")
+            return out[: n.value].copy()
+
+    # ClusterDetections, core/pigo.go:262 -- sorts `detections` in place, returns a fresh slice
+    def ClusterDetections(self, detections: np.ndarray, iouThreshold: float) -> np.ndarray:
+        assert detections.dtype == DET_DTYPE and detections.flags.c_contiguous
+        n = len(detections)
+        out = np.zeros(max(n, 1), dtype=DET_DTYPE)
+        k = C.c_int(0)
+        check(load_library().pigo_cluster_detections(self._need(), detections.ctypes.data, n, float(iouThreshold), out.ctypes.data,
+                                                     len(out), C.byref(k)), "ClusterDetections")
+        return out[: k.value].copy()
+
+
+def NewPigo(device: int = 0) -> Pigo:
+    """core/pigo.go:46"""
+    return Pigo(device=device)

@@ -1,0 +1,974 @@
+// pigo_hip.hip -- host side of libpigo_hip.so: the C ABI declared in include/pigo_hip.h.
+//
+// Built for gfx950 only (see pigo_amd/build.py):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC pigo_hip.hip -o libpigo_hip.so
+//
+// Host responsibilities (everything else is in pigo_kernels.hip.inc):
+//   - Unpack (core/pigo.go:51-110): parse the cascade file, keep host copies, upload the tables
+//   - RunCascade's scale ladder (core/pigo.go:226-231,255) evaluated in float64 exactly as the Go code
+//     does, turned into the flattened (scale,row,col) index space, the tile list and the per-scale
+//     offset tables (built on the GPU by k_build_tab)
+//   - Go's sort.Slice (pdqsort) restated for ClusterDetections' in-place sort (core/pigo.go:264-266)
+//   - plan / workspace management, launches, the status flags and the overflow fallback
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pigo_hip.h"
+#include "pigo_kernels.hip.inc"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+pigo_status fail(pigo_status st, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(PIGO_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count)
+    {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// pigo.go:156-157
+const int kQCos[33] = {256, 251, 236, 212, 181, 142, 97, 49, 0, -49, -97, -142, -181, -212, -236, -251, -256,
+                       -251, -236, -212, -181, -142, -97, -49, 0, 49, 97, 142, 181, 212, 236, 251, 256};
+const int kQSin[33] = {0, 49, 97, 142, 181, 212, 236, 251, 256, 251, 236, 212, 181, 142, 97, 49, 0,
+                       -49, -97, -142, -181, -212, -236, -251, -256, -251, -236, -212, -181, -142, -97, -49, 0};
+
+}  // namespace
+
+// ---- handles ----------------------------------------------------------------------------------------------
+
+struct pigo_plan;
+
+struct pigo_cascade {
+    int device = 0;
+    uint32_t depth = 0, ntrees = 0;
+    int nodes = 0;                       // 2^depth (what RunCascade calls treeDepth, pigo.go:216)
+    std::vector<int8_t> codes;           // treeCodes     [ntrees][4*nodes]
+    std::vector<float> pred;             // treePred      [ntrees][nodes]
+    std::vector<float> thr;              // treeThreshold [ntrees]
+    DevBuf<int8_t> d_codes;
+    DevBuf<float> d_leaf, d_thr;
+    std::mutex mu;                       // serialises the single-frame entry points and the plan cache
+    std::list<std::unique_ptr<pigo_plan>> cache;   // most recently used first
+    // scratch for pigo_run_cascade / pigo_cluster_detections
+    DevBuf<uint8_t> d_frame;
+    DevBuf<pigo_det> d_dets, d_sorted, d_clusters;
+    DevBuf<int32_t> d_small;             // counts etc.
+    DevBuf<float> d_mq;
+};
+
+struct PlanKey {
+    int rows, cols, dim, min_size, max_size;
+    double shift, scale, angle;
+    bool operator==(const PlanKey &o) const
+    {
+        return rows == o.rows && cols == o.cols && dim == o.dim && min_size == o.min_size && max_size == o.max_size &&
+               shift == o.shift && scale == o.scale && angle == o.angle;
+    }
+};
+
+struct pigo_plan {
+    pigo_cascade *c = nullptr;
+    PlanKey key{};
+    int max_frames = 0, det_cap = 0;
+    bool rot = false, guard = false;
+    int angle_idx = 0;
+    int variant = 0;
+    std::vector<ScaleDesc> scales;
+    std::vector<uint32_t> tiles;
+    int n_ladder = 0;
+    long long windows = 0;
+    ScanArgs args{};                     // template for launches (frame pointers filled per run)
+    DevBuf<ScaleDesc> d_scales;
+    DevBuf<uint32_t> d_tiles;
+    DevBuf<int2> d_tab;
+    DevBuf<QEntry> d_queue;
+    DevBuf<uint32_t> d_qcount;
+    DevBuf<RawDet> d_raw;
+    DevBuf<int32_t> d_flags;
+    DevBuf<float> d_mq;
+    long long qcap = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    std::vector<const char *> ev_names;
+    int n_timed = 0;
+    int last_nframes = 0;
+    std::mutex mu;
+    ~pigo_plan()
+    {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
+    size_t workspace_bytes() const
+    {
+        return d_scales.bytes() + d_tiles.bytes() + d_tab.bytes() + d_queue.bytes() + d_qcount.bytes() + d_raw.bytes() + d_flags.bytes() +
+               d_mq.bytes();
+    }
+};
+
+extern "C" const char *pigo_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int pigo_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- Unpack -------------------------------------------------------------------------------------------------
+
+extern "C" pigo_status pigo_cascade_create(const uint8_t *packet, size_t len, int device, pigo_cascade **out)
+{
+    if (!out) return fail(PIGO_ERR_PARAM, "out is NULL");
+    *out = nullptr;
+    if (!packet) return fail(PIGO_ERR_PARAM, "packet is NULL");
+    // pigo.go:61-75: skip 8 bytes, u32 depth, u32 tree count
+    if (len < 16) return fail(PIGO_ERR_PACKET, "Unpack: packet of %zu bytes is shorter than the 16-byte header", len);
+    const uint32_t depth = le32(packet + 8), ntrees = le32(packet + 12);
+    if (depth > 12) return fail(PIGO_ERR_PARAM, "Unpack: tree depth %u not supported (max 12)", depth);
+    const size_t nodes = (size_t)1 << depth;
+    const size_t ncode = 4 * nodes - 4;  // pigo.go:81
+    const size_t rec = ncode + 4 * nodes + 4;
+    if ((len - 16) / rec < ntrees) return fail(PIGO_ERR_PACKET, "Unpack: packet too short for %u trees of depth %u", ntrees, depth);
+
+    std::unique_ptr<pigo_cascade> c(new (std::nothrow) pigo_cascade);
+    if (!c) return fail(PIGO_ERR_NOMEM, "out of memory");
+    c->device = device;
+    c->depth = depth;
+    c->ntrees = ntrees;
+    c->nodes = (int)nodes;
+    c->codes.assign((size_t)ntrees * 4 * nodes, 0);
+    c->pred.resize((size_t)ntrees * nodes);
+    c->thr.resize(ntrees);
+    size_t pos = 16;
+    for (uint32_t t = 0; t < ntrees; ++t) {
+        // pigo.go:79-86: four zero bytes, then the 4*2^d-4 code bytes reinterpreted as int8
+        memcpy(c->codes.data() + (size_t)t * 4 * nodes + 4, packet + pos, ncode);
+        pos += ncode;
+        for (size_t i = 0; i < nodes; ++i) {  // pigo.go:89-95
+            const uint32_t u = le32(packet + pos);
+            memcpy(&c->pred[(size_t)t * nodes + i], &u, 4);
+            pos += 4;
+        }
+        const uint32_t u = le32(packet + pos);  // pigo.go:96-100
+        memcpy(&c->thr[t], &u, 4);
+        pos += 4;
+    }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(PIGO_ERR_HIP, "device %d not available (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(c->d_codes.alloc(c->codes.size()));
+    HIP_TRY(c->d_leaf.alloc(c->pred.size()));
+    HIP_TRY(c->d_thr.alloc(c->thr.size()));
+    if (ntrees) {
+        HIP_TRY(hipMemcpy(c->d_codes.p, c->codes.data(), c->codes.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_leaf.p, c->pred.data(), c->pred.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_thr.p, c->thr.data(), c->thr.size() * 4, hipMemcpyHostToDevice));
+    }
+    *out = c.release();
+    return PIGO_OK;
+}
+
+extern "C" pigo_status pigo_cascade_info(const pigo_cascade *c, uint32_t *tree_depth, uint32_t *tree_num)
+{
+    if (!c) return fail(PIGO_ERR_PARAM, "cascade is NULL");
+    if (tree_depth) *tree_depth = c->depth;
+    if (tree_num) *tree_num = c->ntrees;
+    return PIGO_OK;
+}
+
+extern "C" pigo_status pigo_cascade_tables(const pigo_cascade *c, int8_t *codes, size_t ncodes, float *pred, size_t npred, float *thr,
+                                           size_t nthr)
+{
+    if (!c) return fail(PIGO_ERR_PARAM, "cascade is NULL");
+    if (codes) {
+        if (ncodes < c->codes.size()) return fail(PIGO_ERR_CAPACITY, "codes buffer too small");
+        memcpy(codes, c->codes.data(), c->codes.size());
+    }
+    if (pred) {
+        if (npred < c->pred.size()) return fail(PIGO_ERR_CAPACITY, "pred buffer too small");
+        memcpy(pred, c->pred.data(), c->pred.size() * 4);
+    }
+    if (thr) {
+        if (nthr < c->thr.size()) return fail(PIGO_ERR_CAPACITY, "thr buffer too small");
+        memcpy(thr, c->thr.data(), c->thr.size() * 4);
+    }
+    return PIGO_OK;
+}
+
+extern "C" void pigo_cascade_destroy(pigo_cascade *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    delete c;
+}
+
+// ---- plans ------------------------------------------------------------------------------------------------------
+
+namespace {
+
+// RunCascade's ladder, pigo.go:219-231,255, in the reference's own arithmetic (float64 products, int
+// truncation).  Only rungs that classify at least one window are kept.
+pigo_status build_ladder(pigo_plan &p)
+{
+    const PlanKey &k = p.key;
+    const int rows = k.rows, cols = k.cols;
+    long long scale = k.min_size;  // :219
+    long long nwin = 0;
+    p.scales.clear();
+    p.tiles.clear();
+    p.n_ladder = 0;
+    while (scale <= k.max_size) {  // :226
+        const double m = k.shift * (double)scale;
+        const double mm = m > 1.0 ? m : 1.0;  // math.Max(ShiftFactor*scale, 1)
+        const long long step = mm >= 2147483647.0 ? 2147483647LL : (long long)mm;  // :227 (any step >= the image size behaves the same)
+        const long long off = scale / 2 + 1;  // :228
+        long long nr = 0, nc = 0;
+        if ((long long)rows - off >= off) nr = ((long long)rows - 2 * off) / step + 1;  // :230
+        if ((long long)cols - off >= off) nc = ((long long)cols - 2 * off) / step + 1;  // :231
+        ++p.n_ladder;
+        if (nr > 0 && nc > 0) {
+            if (p.scales.size() >= 2047) return fail(PIGO_ERR_PARAM, "more than 2047 non-empty scales");
+            ScaleDesc sd{};
+            sd.s = (int32_t)scale;
+            sd.step = (int32_t)step;
+            sd.off = (int32_t)off;
+            sd.nr = (int32_t)nr;
+            sd.nc = (int32_t)nc;
+            if (nwin + nr * nc > 0xffffffffLL) return fail(PIGO_ERR_PARAM, "more than 2^32-1 windows per frame");
+            sd.win_base = (uint32_t)nwin;
+            nwin += nr * nc;
+            const uint32_t sidx = (uint32_t)p.scales.size();
+            const long long tys = (nr + kTH - 1) / kTH, txs = (nc + kTW - 1) / kTW;
+            for (long long ty = 0; ty < tys; ++ty)
+                for (long long tx = 0; tx < txs; ++tx) p.tiles.push_back((sidx << 21) | ((uint32_t)ty << 10) | (uint32_t)tx);
+            p.scales.push_back(sd);
+        } else if (scale > 0) {
+            break;  // offsets only grow with the scale: every later rung is empty too
+        }
+        // :255 scale = int(float64(scale) + math.Max(2, float64(scale)*ScaleFactor - float64(scale)))
+        const double grow = (double)scale * k.scale - (double)scale;
+        const double next = (double)scale + (grow > 2.0 ? grow : 2.0);
+        if (next > 4.0e9) break;
+        scale = (long long)next;
+    }
+    p.windows = nwin;
+    return PIGO_OK;
+}
+
+// Compaction points of the cascade: trees whose threshold is a real one (facefinder: 24 of 468; the rest
+// hold the -15 sentinel and never reject).  Correctness does not depend on this choice -- every tree's
+// threshold is tested at every tree -- it only decides where survivors are re-packed.
+void build_stages(pigo_plan &p, int head_stages_wanted)
+{
+    const pigo_cascade &c = *p.c;
+    const int nt = (int)c.ntrees;
+    std::vector<int> ends;
+    float lo = nt ? c.thr[0] : 0.f;
+    for (int i = 0; i < nt; ++i) lo = std::min(lo, c.thr[i]);
+    for (int i = 0; i < nt; ++i)
+        if (c.thr[i] > lo || i == nt - 1) ends.push_back(i);
+    ScanArgs &a = p.args;
+    a.n_head_stages = 0;
+    a.n_tail_stages = 0;
+    a.nh = 0;
+    size_t e = 0;
+    for (; e < ends.size() && a.n_head_stages < std::min(head_stages_wanted, kMaxHeadStages) && ends[e] < kNHMax; ++e) {
+        a.head_end[a.n_head_stages++] = ends[e];
+        a.nh = ends[e] + 1;
+    }
+    if (a.n_head_stages == 0 && nt > 0) {  // first real threshold is deeper than the LDS tables reach
+        a.head_end[0] = std::min(nt, kNHMax) - 1;
+        a.n_head_stages = 1;
+        a.nh = a.head_end[0] + 1;
+        while (e < ends.size() && ends[e] <= a.head_end[0]) ++e;
+    }
+    std::vector<int> tail(ends.begin() + e, ends.end());
+    if (!tail.empty() || a.nh < nt) {
+        if (tail.empty() || tail.back() != nt - 1) tail.push_back(nt - 1);
+        while ((int)tail.size() > kMaxTailStages) {  // merge neighbours until they fit
+            std::vector<int> m;
+            for (size_t i = 1; i < tail.size(); i += 2) m.push_back(tail[i]);
+            if (tail.size() % 2) m.push_back(tail.back());
+            tail.swap(m);
+        }
+        for (int v : tail) a.tail_end[a.n_tail_stages++] = v;
+    }
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+pigo_status plan_alloc_batch(pigo_plan &p, int max_frames, int det_cap)
+{
+    p.max_frames = max_frames;
+    p.det_cap = det_cap;
+    // survivor queue: room for 1/8 of a frame's windows (noise keeps 5.5 % after four trees); an overflow
+    // is detected on the device and answered with the monolithic kernel (pigo_plan_run_sync).
+    long long qcap = std::max<long long>(4096, p.windows / env_int("PIGO_QUEUE_DIV", 8));
+    qcap = std::min<long long>(qcap, std::max<long long>(p.windows, 1));
+    qcap = (qcap + kTailChunk - 1) / kTailChunk * kTailChunk;
+    p.qcap = qcap;
+    HIP_TRY(p.d_queue.alloc((size_t)qcap * max_frames));
+    HIP_TRY(p.d_qcount.alloc(max_frames));
+    HIP_TRY(p.d_raw.alloc((size_t)det_cap * max_frames));
+    HIP_TRY(p.d_mq.alloc((size_t)det_cap * max_frames));
+    return PIGO_OK;
+}
+
+pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int det_cap, std::unique_ptr<pigo_plan> &out)
+{
+    if (!c) return fail(PIGO_ERR_PARAM, "cascade is NULL");
+    if (key.rows < 1 || key.cols < 1 || key.rows >= 65536 || key.cols >= 65536 || key.dim >= 65536)
+        return fail(PIGO_ERR_PARAM, "rows/cols/dim must be in [1, 65535]");
+    if (key.dim < key.cols) return fail(PIGO_ERR_PARAM, "dim (%d) < cols (%d)", key.dim, key.cols);
+    if ((long long)key.rows * key.dim >= 0x7fffffffLL) return fail(PIGO_ERR_PARAM, "frame larger than 2 GiB");
+    if (key.min_size < 0) return fail(PIGO_ERR_PARAM, "min_size < 0 (the reference would index out of range)");
+    if (!std::isfinite(key.shift) || !std::isfinite(key.scale) || !std::isfinite(key.angle))
+        return fail(PIGO_ERR_PARAM, "non-finite shift/scale/angle");
+    if (max_frames < 1 || det_cap < 1) return fail(PIGO_ERR_PARAM, "max_frames and det_cap must be >= 1");
+    if ((long long)max_frames * det_cap > (1LL << 31)) return fail(PIGO_ERR_PARAM, "max_frames * det_cap too large");
+
+    std::unique_ptr<pigo_plan> p(new (std::nothrow) pigo_plan);
+    if (!p) return fail(PIGO_ERR_NOMEM, "out of memory");
+    p->c = c;
+    p->key = key;
+    p->rot = key.angle > 0.0;  // pigo.go:232
+    if (p->rot) {
+        const double a = key.angle > 1.0 ? 1.0 : key.angle;  // pigo.go:233-235
+        p->angle_idx = (int)(32.0 * a);                      // pigo.go:159
+        if (key.rows >= 32768 || key.cols >= 32768) return fail(PIGO_ERR_PARAM, "rotated scan supports images below 32768 pixels per side");
+        // quirk Q1: columns are clamped with nrows-1, so the largest index is (rows-1)*dim + rows-1.  Go
+        // panics when that leaves the pixel slice; the kernels then guard every load and raise the flag.
+        p->guard = (long long)(key.rows - 1) * key.dim + (key.rows - 1) >= (long long)key.rows * key.dim;
+    }
+    pigo_status st = build_ladder(*p);
+    if (st != PIGO_OK) return st;
+
+    HIP_TRY(hipSetDevice(c->device));
+    const int nscales = (int)p->scales.size();
+    HIP_TRY(p->d_scales.alloc(nscales));
+    HIP_TRY(p->d_tiles.alloc(p->tiles.size()));
+    HIP_TRY(p->d_flags.alloc(4));
+    HIP_TRY(hipMemset(p->d_flags.p, 0, 16));
+    const size_t tab_n = (size_t)nscales * c->ntrees * c->nodes;
+    HIP_TRY(p->d_tab.alloc(tab_n));
+    if (nscales) {
+        HIP_TRY(hipMemcpy(p->d_scales.p, p->scales.data(), nscales * sizeof(ScaleDesc), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_tiles.p, p->tiles.data(), p->tiles.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (tab_n) {
+        const int blocks = (int)std::min<size_t>((tab_n + 255) / 256, 4096);
+        k_build_tab<<<blocks, 256>>>(c->d_codes.p, p->d_scales.p, p->d_tab.p, nscales, (int)c->ntrees, c->nodes, key.dim, p->rot ? 1 : 0,
+                                     kQCos[p->angle_idx], kQSin[p->angle_idx]);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    st = plan_alloc_batch(*p, max_frames, det_cap);
+    if (st != PIGO_OK) return st;
+
+    ScanArgs &a = p->args;
+    a.scales = p->d_scales.p;
+    a.tiles = p->d_tiles.p;
+    a.tab = p->d_tab.p;
+    a.leaf = c->d_leaf.p;
+    a.thr = c->d_thr.p;
+    a.queue = p->d_queue.p;
+    a.qcount = p->d_qcount.p;
+    a.raw = p->d_raw.p;
+    a.flags = p->d_flags.p;
+    a.npix = (uint32_t)((long long)key.rows * key.dim);
+    a.dim = key.dim;
+    a.lim = key.rows - 1;
+    a.ntiles = (int)p->tiles.size();
+    a.ntrees = (int)c->ntrees;
+    a.nodes = c->nodes;
+    a.depth = (int)c->depth;
+    a.qcap = (uint32_t)p->qcap;
+    a.det_cap = det_cap;
+    build_stages(*p, env_int("PIGO_HEAD_STAGES", kMaxHeadStages));
+    p->variant = (c->depth == 6 && c->ntrees > 0) ? env_int("PIGO_SCAN_VARIANT", 1) : 0;
+    if (p->variant != 0 && !(c->depth == 6 && c->ntrees > 0)) p->variant = 0;
+    out = std::move(p);
+    return PIGO_OK;
+}
+
+template <bool ROT, bool GUARD, class Mark>
+void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t s, Mark &mark)
+{
+    const uint32_t nb = (uint32_t)a.nframes * (uint32_t)a.ntiles;
+    if (variant == 1) {
+        mark("scan_head");
+        k_scan_head<ROT, GUARD><<<nb, kThreads, 0, s>>>(a);
+        if (a.n_tail_stages > 0) {
+            mark("scan_tail");
+            k_scan_tail<ROT, GUARD><<<(uint32_t)a.nframes * (uint32_t)a.tail_wgs, kThreads, 0, s>>>(a);
+        }
+    } else {
+        mark("scan_mono");
+        k_scan_mono<ROT, GUARD><<<nb, kThreads, 0, s>>>(a);
+    }
+    (void)p;
+}
+
+pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame_stride, int nframes, pigo_det *d_dets, int32_t *d_counts,
+                             hipStream_t s, int variant)
+{
+    if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
+    if (nframes < 0 || nframes > p->max_frames) return fail(PIGO_ERR_PARAM, "nframes %d outside [0, %d]", nframes, p->max_frames);
+    if (nframes == 0) return PIGO_OK;
+    if (!d_frames || !d_dets || !d_counts) return fail(PIGO_ERR_PARAM, "NULL device pointer");
+    if (frame_stride < (size_t)p->key.rows * p->key.dim) return fail(PIGO_ERR_PARAM, "frame_stride smaller than rows*dim");
+    HIP_TRY(hipSetDevice(p->c->device));
+    HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nframes * 4, s));
+    p->last_nframes = nframes;
+    p->n_timed = 0;
+    if (p->scales.empty() || p->c->ntrees == 0) return PIGO_OK;  // no window is classified / classifyRegion returns 0.0 (pigo.go:146)
+
+    ScanArgs a = p->args;
+    a.frames = d_frames;
+    a.frame_stride = frame_stride;
+    a.nframes = nframes;
+    a.counts = d_counts;
+    a.tail_wgs = std::max(8, std::min(256, 2048 / nframes));
+    if (variant == 1) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)nframes * 4, s));
+
+    size_t ev = 0;
+    auto mark = [&](const char *name) {
+        if (!p->profiling) return;
+        if (ev >= p->events.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            p->events.push_back(e);
+            p->ev_names.push_back(name);
+        }
+        p->ev_names[ev] = name;
+        (void)hipEventRecord(p->events[ev], s);
+        ++ev;
+    };
+    if (p->rot) {
+        if (p->guard)
+            launch_scan<true, true>(*p, a, variant, s, mark);
+        else
+            launch_scan<true, false>(*p, a, variant, s, mark);
+    } else {
+        launch_scan<false, false>(*p, a, variant, s, mark);
+    }
+    mark("restore_order");
+    {
+        dim3 grid((unsigned)((p->det_cap + kThreads - 1) / kThreads), (unsigned)nframes);
+        k_restore_order<<<grid, kThreads, 0, s>>>(p->d_raw.p, d_counts, p->det_cap, d_dets);
+    }
+    mark("end");
+    p->n_timed = (int)ev;
+    HIP_TRY(hipGetLastError());
+    return PIGO_OK;
+}
+
+}  // namespace
+
+extern "C" pigo_status pigo_plan_create(pigo_cascade *c, int rows, int cols, int dim, int min_size, int max_size, double shift_factor,
+                                        double scale_factor, double angle, int max_frames, int det_cap, pigo_plan **out)
+{
+    if (!out) return fail(PIGO_ERR_PARAM, "out is NULL");
+    *out = nullptr;
+    std::unique_ptr<pigo_plan> p;
+    PlanKey key{rows, cols, dim, min_size, max_size, shift_factor, scale_factor, angle};
+    pigo_status st = plan_build(c, key, max_frames, det_cap, p);
+    if (st != PIGO_OK) return st;
+    *out = p.release();
+    return PIGO_OK;
+}
+
+extern "C" void pigo_plan_destroy(pigo_plan *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->c->device);
+    delete p;
+}
+
+extern "C" pigo_status pigo_plan_info(const pigo_plan *p, pigo_plan_info_t *info)
+{
+    if (!p || !info) return fail(PIGO_ERR_PARAM, "NULL argument");
+    info->windows_per_frame = p->windows;
+    info->n_scales = (int32_t)p->scales.size();
+    info->n_ladder = p->n_ladder;
+    info->tiles_per_frame = (int32_t)p->tiles.size();
+    info->n_head_trees = p->args.nh;
+    info->variant = p->variant;
+    info->max_frames = p->max_frames;
+    info->det_cap = p->det_cap;
+    info->queue_capacity = p->qcap;
+    info->workspace_bytes = (int64_t)p->workspace_bytes();
+    return PIGO_OK;
+}
+
+extern "C" pigo_status pigo_plan_set_variant(pigo_plan *p, int variant)
+{
+    if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
+    if (variant != 0 && variant != 1) return fail(PIGO_ERR_PARAM, "variant must be 0 or 1");
+    if (variant == 1 && !(p->c->depth == 6 && p->c->ntrees > 0)) return fail(PIGO_ERR_PARAM, "variant 1 needs a depth-6 cascade");
+    p->variant = variant;
+    return PIGO_OK;
+}
+
+extern "C" pigo_status pigo_plan_run(pigo_plan *p, const uint8_t *d_frames, size_t frame_stride, int nframes, pigo_det *d_dets,
+                                     int32_t *d_counts, void *stream)
+{
+    if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
+    return plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, (hipStream_t)stream, p->variant);
+}
+
+extern "C" pigo_status pigo_plan_status(pigo_plan *p)
+{
+    if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
+    HIP_TRY(hipSetDevice(p->c->device));
+    int32_t flags[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(flags, p->d_flags.p, 16, hipMemcpyDeviceToHost));
+    if (flags[0] || flags[1]) HIP_TRY(hipMemset(p->d_flags.p, 0, 16));
+    if (flags[1]) return fail(PIGO_ERR_PANIC, "the reference would panic: pixel index out of range in classifyRotatedRegion (pigo.go:167-179)");
+    if (flags[0]) return fail(PIGO_ERR_CAPACITY, "survivor queue overflow");
+    return PIGO_OK;
+}
+
+extern "C" pigo_status pigo_plan_run_sync(pigo_plan *p, const uint8_t *d_frames, size_t frame_stride, int nframes, pigo_det *d_dets,
+                                          int32_t *d_counts, void *stream)
+{
+    if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    pigo_status st = plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, s, p->variant);
+    if (st != PIGO_OK) return st;
+    HIP_TRY(hipStreamSynchronize(s));
+    st = pigo_plan_status(p);
+    if (st == PIGO_ERR_CAPACITY && p->variant == 1) {  // pathological frame: more survivors than the queue holds
+        st = plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, s, 0);
+        if (st != PIGO_OK) return st;
+        HIP_TRY(hipStreamSynchronize(s));
+        st = pigo_plan_status(p);
+    }
+    return st;
+}
+
+extern "C" pigo_status pigo_plan_set_profiling(pigo_plan *p, int on)
+{
+    if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
+    p->profiling = on != 0;
+    return PIGO_OK;
+}
+
+extern "C" int pigo_plan_last_timings(pigo_plan *p, const char **names, float *ms, int cap)
+{
+    if (!p || p->n_timed < 2) return 0;
+    (void)hipSetDevice(p->c->device);
+    int n = 0;
+    for (int i = 0; i + 1 < p->n_timed && n < cap; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, p->events[i], p->events[i + 1]) != hipSuccess) return n;
+        names[n] = p->ev_names[i];
+        ms[n] = t;
+        ++n;
+    }
+    return n;
+}
+
+extern "C" pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n)
+{
+    if (!p || !n) return fail(PIGO_ERR_PARAM, "NULL argument");
+    HIP_TRY(hipSetDevice(p->c->device));
+    std::vector<uint32_t> h((size_t)std::max(1, p->last_nframes));
+    *n = 0;
+    if (p->last_nframes == 0) return PIGO_OK;
+    HIP_TRY(hipMemcpy(h.data(), p->d_qcount.p, (size_t)p->last_nframes * 4, hipMemcpyDeviceToHost));
+    for (uint32_t v : h) *n += v;
+    return PIGO_OK;
+}
+
+// ---- ClusterDetections ----------------------------------------------------------------------------------------------
+
+extern "C" pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, const int32_t *d_counts, int nframes, double iou_threshold,
+                                         pigo_det *d_sorted, pigo_det *d_clusters, int32_t *d_ccounts, int32_t *d_ties, void *stream)
+{
+    if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
+    if (nframes < 0 || nframes > p->max_frames) return fail(PIGO_ERR_PARAM, "nframes outside the plan's range");
+    if (nframes == 0) return PIGO_OK;
+    if (!d_dets || !d_counts || !d_sorted || !d_clusters || !d_ccounts) return fail(PIGO_ERR_PARAM, "NULL device pointer");
+    if (p->det_cap > 65536) return fail(PIGO_ERR_PARAM, "GPU clustering supports det_cap <= 65536");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(p->c->device));
+    if (d_ties) HIP_TRY(hipMemsetAsync(d_ties, 0, (size_t)nframes * 4, s));
+    dim3 grid((unsigned)((p->det_cap + kThreads - 1) / kThreads), (unsigned)nframes);
+    k_sort_by_q<<<grid, kThreads, 0, s>>>(d_dets, d_counts, p->det_cap, d_sorted, d_ties);
+    if (p->det_cap <= 256 * 64)
+        k_cluster<256><<<nframes, 256, 0, s>>>(d_sorted, d_counts, p->det_cap, iou_threshold, d_clusters, d_ccounts, p->d_mq.p);
+    else
+        k_cluster<1024><<<nframes, 1024, 0, s>>>(d_sorted, d_counts, p->det_cap, iou_threshold, d_clusters, d_ccounts, p->d_mq.p);
+    HIP_TRY(hipGetLastError());
+    return PIGO_OK;
+}
+
+// Go's sort.Slice (sort/zsortfunc.go, Go 1.19-1.22: pattern-defeating quicksort) specialised to
+// `detections[i].Q < detections[j].Q`  (pigo.go:264-266).  It is unstable, so the order of tied Q values
+// is a property of this exact algorithm; see DESIGN.md "Ties".
+namespace gosort {
+
+struct Data {
+    pigo_det *d;
+    bool less(long i, long j) const { return d[i].q < d[j].q; }
+    void swap(long i, long j) const { std::swap(d[i], d[j]); }
+};
+
+void insertion_sort(const Data &x, long a, long b)
+{
+    for (long i = a + 1; i < b; ++i)
+        for (long j = i; j > a && x.less(j, j - 1); --j) x.swap(j, j - 1);
+}
+
+void sift_down(const Data &x, long lo, long hi, long first)
+{
+    long root = lo;
+    for (;;) {
+        long child = 2 * root + 1;
+        if (child >= hi) return;
+        if (child + 1 < hi && x.less(first + child, first + child + 1)) ++child;
+        if (!x.less(first + root, first + child)) return;
+        x.swap(first + root, first + child);
+        root = child;
+    }
+}
+
+void heap_sort(const Data &x, long a, long b)
+{
+    const long first = a, lo = 0, hi = b - a;
+    for (long i = (hi - 1) / 2; i >= 0; --i) sift_down(x, i, hi, first);
+    for (long i = hi - 1; i >= 0; --i) {
+        x.swap(first, first + i);
+        sift_down(x, lo, i, first);
+    }
+}
+
+long partition(const Data &x, long a, long b, long pivot, bool &already)
+{
+    x.swap(a, pivot);
+    long i = a + 1, j = b - 1;
+    while (i <= j && x.less(i, a)) ++i;
+    while (i <= j && !x.less(j, a)) --j;
+    if (i > j) {
+        x.swap(j, a);
+        already = true;
+        return j;
+    }
+    x.swap(i, j);
+    ++i;
+    --j;
+    for (;;) {
+        while (i <= j && x.less(i, a)) ++i;
+        while (i <= j && !x.less(j, a)) --j;
+        if (i > j) break;
+        x.swap(i, j);
+        ++i;
+        --j;
+    }
+    x.swap(j, a);
+    already = false;
+    return j;
+}
+
+long partition_equal(const Data &x, long a, long b, long pivot)
+{
+    x.swap(a, pivot);
+    long i = a + 1, j = b - 1;
+    for (;;) {
+        while (i <= j && !x.less(a, i)) ++i;
+        while (i <= j && x.less(a, j)) --j;
+        if (i > j) break;
+        x.swap(i, j);
+        ++i;
+        --j;
+    }
+    return i;
+}
+
+bool partial_insertion_sort(const Data &x, long a, long b)
+{
+    const long max_steps = 5, shortest_shifting = 50;
+    long i = a + 1;
+    for (long step = 0; step < max_steps; ++step) {
+        while (i < b && !x.less(i, i - 1)) ++i;
+        if (i == b) return true;
+        if (b - a < shortest_shifting) return false;
+        x.swap(i, i - 1);
+        if (i - a >= 2)
+            for (long j = i - 1; j >= 1; --j) {
+                if (!x.less(j, j - 1)) break;
+                x.swap(j, j - 1);
+            }
+        if (b - i >= 2)
+            for (long j = i + 1; j < b; ++j) {
+                if (!x.less(j, j - 1)) break;
+                x.swap(j, j - 1);
+            }
+    }
+    return false;
+}
+
+int bits_len(unsigned long long v)
+{
+    int n = 0;
+    for (; v; v >>= 1) ++n;
+    return n;
+}
+
+void break_patterns(const Data &x, long a, long b)
+{
+    const long length = b - a;
+    if (length >= 8) {
+        unsigned long long rnd = (unsigned long long)length;
+        const unsigned long long modulus = 1ull << bits_len((unsigned long long)length);
+        const long idx = a + (length / 4) * 2 - 1;
+        for (long i = 0; i < 3; ++i) {
+            rnd ^= rnd << 13;
+            rnd ^= rnd >> 7;
+            rnd ^= rnd << 17;
+            long other = (long)(rnd & (modulus - 1));
+            if (other >= length) other -= length;
+            x.swap(idx - 1 + i, a + other);
+        }
+    }
+}
+
+void order2(const Data &x, long &a, long &b, long &swaps)
+{
+    if (x.less(b, a)) {
+        ++swaps;
+        std::swap(a, b);
+    }
+}
+
+long median(const Data &x, long a, long b, long c, long &swaps)
+{
+    order2(x, a, b, swaps);
+    order2(x, b, c, swaps);
+    order2(x, a, b, swaps);
+    return b;
+}
+
+enum Hint { kUnknown, kIncreasing, kDecreasing };
+
+long choose_pivot(const Data &x, long a, long b, Hint &hint)
+{
+    const long shortest_ninther = 50, max_swaps = 4 * 3;
+    const long l = b - a;
+    long swaps = 0;
+    long i = a + l / 4 * 1, j = a + l / 4 * 2, k = a + l / 4 * 3;
+    if (l >= 8) {
+        if (l >= shortest_ninther) {
+            i = median(x, i - 1, i, i + 1, swaps);
+            j = median(x, j - 1, j, j + 1, swaps);
+            k = median(x, k - 1, k, k + 1, swaps);
+        }
+        j = median(x, i, j, k, swaps);
+    }
+    hint = swaps == 0 ? kIncreasing : swaps == max_swaps ? kDecreasing : kUnknown;
+    return j;
+}
+
+void reverse_range(const Data &x, long a, long b)
+{
+    for (long i = a, j = b - 1; i < j; ++i, --j) x.swap(i, j);
+}
+
+void pdqsort(const Data &x, long a, long b, long limit)
+{
+    const long max_insertion = 12;
+    bool was_balanced = true, was_partitioned = true;
+    for (;;) {
+        const long length = b - a;
+        if (length <= max_insertion) {
+            insertion_sort(x, a, b);
+            return;
+        }
+        if (limit == 0) {
+            heap_sort(x, a, b);
+            return;
+        }
+        if (!was_balanced) {
+            break_patterns(x, a, b);
+            --limit;
+        }
+        Hint hint;
+        long pivot = choose_pivot(x, a, b, hint);
+        if (hint == kDecreasing) {
+            reverse_range(x, a, b);
+            pivot = (b - 1) - (pivot - a);
+            hint = kIncreasing;
+        }
+        if (was_balanced && was_partitioned && hint == kIncreasing && partial_insertion_sort(x, a, b)) return;
+        if (a > 0 && !x.less(a - 1, pivot)) {
+            a = partition_equal(x, a, b, pivot);
+            continue;
+        }
+        bool already = false;
+        const long mid = partition(x, a, b, pivot, already);
+        was_partitioned = already;
+        const long left = mid - a, right = b - mid, balance = length / 8;
+        if (left < right) {
+            was_balanced = left >= balance;
+            pdqsort(x, a, mid, limit);
+            a = mid + 1;
+        } else {
+            was_balanced = right >= balance;
+            pdqsort(x, mid + 1, b, limit);
+            b = mid;
+        }
+    }
+}
+
+}  // namespace gosort
+
+extern "C" void pigo_sort_by_q(pigo_det *dets, int n)
+{
+    if (!dets || n <= 1) return;
+    gosort::Data x{dets};
+    gosort::pdqsort(x, 0, n, gosort::bits_len((unsigned long long)n));
+}
+
+extern "C" pigo_status pigo_cluster_detections(pigo_cascade *c, pigo_det *dets, int n, double iou_threshold, pigo_det *out, int cap,
+                                               int *n_out)
+{
+    if (!c) return fail(PIGO_ERR_PARAM, "cascade is NULL");
+    if (n_out) *n_out = 0;
+    if (n < 0 || (n > 0 && !dets)) return fail(PIGO_ERR_PARAM, "bad detection list");
+    if (n > 65536) return fail(PIGO_ERR_PARAM, "ClusterDetections: more than 65536 detections");
+    if (n == 0) return PIGO_OK;  // clusters := []Detection{}  (pigo.go:280)
+    pigo_sort_by_q(dets, n);     // pigo.go:264-266, in place like the reference
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->d_sorted.n < (size_t)n) HIP_TRY(c->d_sorted.alloc(n));
+    if (c->d_clusters.n < (size_t)n) HIP_TRY(c->d_clusters.alloc(n));
+    if (c->d_mq.n < (size_t)n) HIP_TRY(c->d_mq.alloc(n));
+    if (c->d_small.n < 4) HIP_TRY(c->d_small.alloc(4));
+    const int32_t h_small[2] = {n, 0};
+    HIP_TRY(hipMemcpy(c->d_small.p, h_small, 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_sorted.p, dets, (size_t)n * sizeof(pigo_det), hipMemcpyHostToDevice));
+    if (n <= 256 * 64)
+        k_cluster<256><<<1, 256>>>(c->d_sorted.p, c->d_small.p, n, iou_threshold, c->d_clusters.p, c->d_small.p + 1, c->d_mq.p);
+    else
+        k_cluster<1024><<<1, 1024>>>(c->d_sorted.p, c->d_small.p, n, iou_threshold, c->d_clusters.p, c->d_small.p + 1, c->d_mq.p);
+    HIP_TRY(hipGetLastError());
+    int32_t ncl = 0;
+    HIP_TRY(hipMemcpy(&ncl, c->d_small.p + 1, 4, hipMemcpyDeviceToHost));
+    if (n_out) *n_out = ncl;
+    if (ncl > cap) return fail(PIGO_ERR_CAPACITY, "ClusterDetections: %d clusters, capacity %d", ncl, cap);
+    if (ncl > 0) {
+        if (!out) return fail(PIGO_ERR_PARAM, "out is NULL");
+        HIP_TRY(hipMemcpy(out, c->d_clusters.p, (size_t)ncl * sizeof(pigo_det), hipMemcpyDeviceToHost));
+    }
+    return PIGO_OK;
+}
+
+// ---- RunCascade (one frame, host memory) ----------------------------------------------------------------------------------
+
+extern "C" pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, size_t npixels, int rows, int cols, int dim, int min_size,
+                                        int max_size, double shift_factor, double scale_factor, double angle, pigo_det *out, int cap,
+                                        int *n_out)
+{
+    if (!c) return fail(PIGO_ERR_PARAM, "cascade is NULL");
+    if (n_out) *n_out = 0;
+    if (!pixels) return fail(PIGO_ERR_PARAM, "pixels is NULL");
+    if (cap < 0 || (cap > 0 && !out)) return fail(PIGO_ERR_PARAM, "bad output buffer");
+    if (rows >= 1 && dim >= 1 && npixels < (size_t)rows * (size_t)dim)
+        return fail(PIGO_ERR_PARAM, "len(pixels)=%zu < rows*dim=%zu", npixels, (size_t)rows * (size_t)dim);
+    std::lock_guard<std::mutex> lock(c->mu);
+    PlanKey key{rows, cols, dim, min_size, max_size, shift_factor, scale_factor, angle};
+    pigo_plan *p = nullptr;
+    for (auto it = c->cache.begin(); it != c->cache.end(); ++it) {
+        if ((*it)->key == key) {
+            c->cache.splice(c->cache.begin(), c->cache, it);
+            p = c->cache.front().get();
+            break;
+        }
+    }
+    int det_cap = std::max(cap, 4096);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!p || p->det_cap < det_cap) {
+            if (p) c->cache.pop_front();
+            std::unique_ptr<pigo_plan> np;
+            pigo_status st = plan_build(c, key, 1, det_cap, np);
+            if (st != PIGO_OK) return st;
+            c->cache.push_front(std::move(np));
+            while (c->cache.size() > 4) c->cache.pop_back();
+            p = c->cache.front().get();
+        }
+        HIP_TRY(hipSetDevice(c->device));
+        const size_t fbytes = (size_t)rows * (size_t)dim;
+        if (c->d_frame.n < fbytes) HIP_TRY(c->d_frame.alloc(fbytes));
+        if (c->d_dets.n < (size_t)p->det_cap) HIP_TRY(c->d_dets.alloc(p->det_cap));
+        if (c->d_small.n < 4) HIP_TRY(c->d_small.alloc(4));
+        HIP_TRY(hipMemcpy(c->d_frame.p, pixels, fbytes, hipMemcpyHostToDevice));
+        pigo_status st = pigo_plan_run_sync(p, c->d_frame.p, fbytes, 1, c->d_dets.p, c->d_small.p, nullptr);
+        if (st != PIGO_OK) return st;
+        int32_t n = 0;
+        HIP_TRY(hipMemcpy(&n, c->d_small.p, 4, hipMemcpyDeviceToHost));
+        if (n > p->det_cap) {  // internal buffer too small: grow once and rescan
+            det_cap = n;
+            continue;
+        }
+        if (n_out) *n_out = n;
+        if (n > cap) return fail(PIGO_ERR_CAPACITY, "RunCascade: %d detections, capacity %d", n, cap);
+        if (n > 0) HIP_TRY(hipMemcpy(out, c->d_dets.p, (size_t)n * sizeof(pigo_det), hipMemcpyDeviceToHost));
+        return PIGO_OK;
+    }
+    return fail(PIGO_ERR_CAPACITY, "RunCascade: detection count kept growing");
+}

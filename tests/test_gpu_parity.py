@@ -1,0 +1,267 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed goldens.
+
+Bar: integer (row, col, scale) bit-exact, in the reference's order; |dq| <= 1e-5 -- the
+implementation targets 0 ulp, so raw-detection q is compared bit-for-bit (Q_TOL_RAW = 0.0) and cluster q,
+a float32 sum reproduced in the reference's order, likewise; the 1e-5 contract tolerance is asserted
+separately so a future relaxation of the design target does not silently weaken the contract.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from pigo_amd import core, synth
+
+from conftest import assert_same_dets, f32_from_hex, golden_image
+
+pytestmark = pytest.mark.gpu
+
+Q_TOL_CONTRACT = 1e-5  # north_star: "within 1e-5 on the float q score"
+Q_TOL_RAW = 0.0        # design target: bit-exact
+
+
+def _cp(img, rows, cols, dim, mn, mx, shift, scale):
+    return core.CascadeParams(MinSize=mn, MaxSize=mx, ShiftFactor=shift, ScaleFactor=scale,
+                              ImageParams=core.ImageParams(Pixels=img, Rows=rows, Cols=cols, Dim=dim))
+
+
+def _golden_dets(rows):
+    return core.make_dets([(r, c, s, f32_from_hex(q)) for r, c, s, q in rows])
+
+
+def _as_core(d):
+    return core.make_dets([(int(a["row"]), int(a["col"]), int(a["scale"]), a["q"]) for a in d])
+
+
+def _as_oracle(d):
+    return oracle.make_dets([(int(a["row"]), int(a["col"]), int(a["scale"]), a["q"]) for a in d])
+
+
+# ---- Unpack -------------------------------------------------------------------------------------------------
+
+
+def test_unpack_tables_match_oracle(pg, orc):
+    assert pg.treeDepth == orc.tree_depth == 6 and pg.treeNum == orc.tree_num == 468
+    for a, b in zip(pg.tables(), orc.tables()):
+        assert a.shape == b.shape and (a == b).all()
+
+
+# ---- RunCascade + ClusterDetections against the goldens (both scan variants) -----------------------------------
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+def test_golden_cases(pg, golden, variant, monkeypatch):
+    monkeypatch.setenv("PIGO_SCAN_VARIANT", str(variant))
+    fresh = core.NewPigo(0).Unpack(synth.facefinder_bytes())  # new handle: plans are cached per handle
+    for case in golden["cases"]:
+        img = golden_image(case["name"])
+        cp = _cp(img, case["rows"], case["cols"], case["dim"], case["min_size"], case["max_size"], case["shift"], case["scale"])
+        dets = fresh.RunCascade(cp, case["angle"])
+        assert_same_dets(dets, _golden_dets(case["detections"]), f"{case['name']} v{variant}", Q_TOL_RAW)
+        assert_same_dets(dets, _golden_dets(case["detections"]), f"{case['name']} v{variant}", Q_TOL_CONTRACT)
+        cl = fresh.ClusterDetections(dets, case["iou"])
+        assert_same_dets(cl, _golden_dets(case["clusters"]), f"{case['name']} clusters", Q_TOL_RAW)
+
+
+def test_reference_test_invariants(pg, gray):
+    """core/pigo_test.go:68-84 and core/flploc_test.go:102-153, run through the product."""
+    dets = pg.RunCascade(_cp(gray, 400, 320, 320, 20, 1000, 0.2, 1.1), 0.0)
+    cl = pg.ClusterDetections(dets, 0.1)
+    assert len(cl) > 0 and int((cl["scale"] > 50).sum()) == 1
+
+
+# ---- seeded sweeps against the oracle -------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+def test_random_parameter_sweep(orc, variant, monkeypatch):
+    monkeypatch.setenv("PIGO_SCAN_VARIANT", str(variant))
+    fresh = core.NewPigo(0).Unpack(synth.facefinder_bytes())
+    rng = np.random.default_rng(2024 + variant)
+    for k in range(14):
+        rows, cols = int(rng.integers(30, 360)), int(rng.integers(30, 480))
+        dim = cols + int(rng.integers(0, 17))
+        img = np.full((rows, dim), 200, dtype=np.uint8)
+        kind = synth.syn_faces if k % 3 else synth.syn_noise
+        img[:, :cols] = kind(rows, cols, seed=31, frame_index=k)
+        mn, mx = int(rng.integers(0, 60)), int(rng.integers(20, 700))
+        shift = float(rng.choice([0.02, 0.05, 0.1, 0.15, 0.2, 0.5]))
+        scale = float(rng.choice([1.0, 1.03, 1.05, 1.1, 1.15, 1.3, 2.0]))
+        angle = float(rng.choice([0.0, 0.0, 0.0, 0.03, 0.125, 0.5, 0.8, 1.0, 1.7, -0.3]))
+        want = orc.run_cascade(img, rows, cols, dim, mn, mx, shift, scale, angle)
+        got = fresh.RunCascade(_cp(img, rows, cols, dim, mn, mx, shift, scale), angle)
+        assert_same_dets(got, want, f"sweep {k}: {rows}x{cols} dim {dim} [{mn},{mx}] {shift}/{scale} a={angle} v{variant}", Q_TOL_RAW)
+        iou = float(rng.choice([0.0, 0.01, 0.1, 0.15, 0.2]))  # thresholds used by the reference's callers (Appendix E)
+        wc, ties = orc.cluster_detections(want.copy(), iou, want_ties=True)
+        gc = fresh.ClusterDetections(got, iou)
+        assert_same_dets(gc, wc, f"sweep {k} clusters (ties={ties})", Q_TOL_RAW)
+
+
+def test_edge_cases(pg, orc):
+    # image smaller than the smallest window: the ladder is empty -> no detections, no error (pigo.go:230)
+    tiny = synth.syn_noise(12, 12, seed=1)
+    assert len(pg.RunCascade(_cp(tiny, 12, 12, 12, 20, 1000, 0.1, 1.1), 0.0)) == 0
+    # MaxSize < MinSize: the loop never runs
+    img = synth.syn_faces(120, 160, seed=3)
+    assert len(pg.RunCascade(_cp(img, 120, 160, 160, 50, 20, 0.1, 1.1), 0.0)) == 0
+    # a single scale, a single row / column of windows
+    for rows, cols, s in ((41, 200, 38), (200, 41, 38), (41, 41, 38)):
+        im = synth.syn_faces(rows, cols, seed=5)
+        want = orc.run_cascade(im, rows, cols, cols, s, s, 0.1, 1.1, 0.0)
+        assert_same_dets(pg.RunCascade(_cp(im, rows, cols, cols, s, s, 0.1, 1.1), 0.0), want, f"single {rows}x{cols}")
+    # scale factor <= 1 still terminates (grows by 2, pigo.go:255), shift tiny -> step 1
+    im = synth.syn_faces(90, 90, seed=6)
+    want = orc.run_cascade(im, 90, 90, 90, 20, 60, 0.001, 0.5, 0.0)
+    assert_same_dets(pg.RunCascade(_cp(im, 90, 90, 90, 20, 60, 0.001, 0.5), 0.0), want, "scale<1")
+    # flat image: every window dies at tree 0; all-255 / all-0
+    for v in (0, 255):
+        flat = np.full((100, 100), v, dtype=np.uint8)
+        assert len(pg.RunCascade(_cp(flat, 100, 100, 100, 20, 1000, 0.1, 1.1), 0.0)) == 0
+    # parameter errors instead of undefined behaviour
+    with pytest.raises(ValueError):
+        pg.RunCascade(_cp(im, 90, 90, 80, 20, 60, 0.1, 1.1), 0.0)  # dim < cols
+    with pytest.raises(ValueError):
+        pg.RunCascade(_cp(im[:40], 90, 90, 90, 20, 60, 0.1, 1.1), 0.0)  # len(pixels) < rows*dim
+    with pytest.raises(ValueError):
+        pg.RunCascade(_cp(im, 90, 90, 90, 20, 60, float("nan"), 1.1), 0.0)
+
+
+def test_rotated_portrait_reads_like_go(pg, orc, gray):
+    """Quirk Q1 on a portrait frame: columns clamp at nrows-1, i.e. the scan reads into the next row -- the
+    guarded kernel must give the oracle's answer and must not raise."""
+    for a in (0.1, 0.8, 1.0):
+        want = orc.run_cascade(gray, 400, 320, 320, 20, 1000, 0.1, 1.1, a)
+        assert_same_dets(pg.RunCascade(_cp(gray, 400, 320, 320, 20, 1000, 0.1, 1.1), a), want, f"portrait a={a}", Q_TOL_RAW)
+
+
+def test_cluster_semantics_and_ties(pg, orc):
+    # hand-made lists, including the quirk-Q5 chain and exact Q ties (order then depends on Go's pdqsort,
+    # which both sides restate; n <= 12 is the stable insertion-sort regime)
+    lists = [
+        [],
+        [(100, 100, 50, 1.0)],
+        [(100, 100, 50, 1.0), (104, 100, 50, 2.0), (108, 100, 50, 3.0), (300, 300, 40, 4.0)],
+        [(100, 100, 100, 1.0), (100, 140, 100, 2.0), (100, 180, 100, 3.0)],
+        [(10, 10, 20, 2.5), (11, 10, 20, 2.5), (200, 200, 20, 2.5), (201, 200, 20, 2.5), (12, 10, 20, 1.0)],
+    ]
+    for rows in lists:
+        for iou in (0.0, 0.01, 0.1, 0.2, 0.5, 1.0):
+            a, b = core.make_dets(rows), oracle.make_dets(rows)
+            got, want = pg.ClusterDetections(a, iou), orc.cluster_detections(b, iou)
+            assert_same_dets(got, want, f"clusters of {rows} @ {iou}", Q_TOL_RAW)
+            assert_same_dets(a, b, "in-place sorted input", Q_TOL_RAW)  # the reference sorts the caller's slice
+    # large tie-heavy list: thousands of detections on a grid with few distinct Q values
+    rng = np.random.default_rng(9)
+    n = 3000
+    rows = [(int(rng.integers(50, 1000)), int(rng.integers(50, 1800)), int(rng.choice([40, 60, 90, 140])),
+             float(rng.integers(1, 40)) / 4.0) for _ in range(n)]
+    a, b = core.make_dets(rows), oracle.make_dets(rows)
+    got, want = pg.ClusterDetections(a, 0.2), orc.cluster_detections(b, 0.2)
+    assert_same_dets(a, b, "sorted 3000", Q_TOL_RAW)
+    assert_same_dets(got, want, "clusters of 3000", Q_TOL_RAW)
+
+
+# ---- full-size configs (BASELINE.json configs 2, 4, 5) ------------------------------------------------------------
+
+
+def test_1080p_config2_and_4_against_oracle(pg, orc):
+    for kind in ("faces", "noise"):
+        f = synth.make_frames(kind, 1, 1080, 1920, seed=1234)[0]
+        for angle in (0.0, 0.8):
+            want = orc.run_cascade(f, 1080, 1920, 1920, 20, 1000, 0.1, 1.1, angle)
+            got = pg.RunCascade(_cp(f, 1080, 1920, 1920, 20, 1000, 0.1, 1.1), angle)
+            assert_same_dets(got, want, f"1080p {kind} angle={angle}", Q_TOL_RAW)
+            wc = orc.cluster_detections(want.copy(), 0.2)
+            assert_same_dets(pg.ClusterDetections(got, 0.2), wc, f"1080p {kind} clusters", Q_TOL_RAW)
+
+
+def test_batch_api_matches_single_frame_and_is_order_stable(pg, orc):
+    """pigo_plan_run on HBM-resident frames: every frame of a batch equals its own RunCascade result, for
+    both scan variants, with a batch size that exercises the XCD frame dealing (13 = 8 + 5)."""
+    import torch
+    from pigo_amd import batch
+    n, rows, cols = 13, 270, 480
+    frames = synth.make_frames("faces", n, rows, cols, seed=77)
+    dev = torch.device("cuda", 0)
+    d_frames = torch.from_numpy(frames).to(dev)
+    want = [orc.run_cascade(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1, 0.0) for f in range(n)]
+    for variant in (1, 0):
+        plan = batch.ScanPlan(pg, rows, cols, MinSize=20, MaxSize=1000, ShiftFactor=0.1, ScaleFactor=1.1, max_frames=n, det_cap=512)
+        plan.set_variant(variant)
+        dets, counts = plan.alloc_outputs(n)
+        for rep in range(2):  # rerun on the same buffers: counters must be reset by the run itself
+            plan.run(d_frames, dets, counts)
+            torch.cuda.synchronize()
+            plan.status()
+            got = batch.dets_to_numpy(dets, counts)
+            for f in range(n):
+                assert_same_dets(got[f], want[f], f"batch frame {f} v{variant} rep{rep}", Q_TOL_RAW)
+        inf = plan.info()
+        assert inf.variant == variant and inf.windows_per_frame > 0
+        # GPU-side per-frame clustering (stable sort; equal to Go's on tie-free lists)
+        sorted_, clusters, ccounts, ties = plan.cluster(dets, counts, 0.2)
+        torch.cuda.synchronize()
+        cl = batch.dets_to_numpy(clusters, ccounts)
+        srt = batch.dets_to_numpy(sorted_, counts)
+        for f in range(n):
+            w = want[f].copy()
+            wc, wties = orc.cluster_detections(w, 0.2, want_ties=True)
+            assert int(ties[f]) == wties
+            if wties == 0:
+                assert_same_dets(cl[f], wc, f"batch clusters frame {f}", Q_TOL_RAW)
+                assert_same_dets(srt[f], w, f"batch sorted frame {f}", Q_TOL_RAW)
+
+
+def test_queue_overflow_falls_back_to_monolithic(orc, monkeypatch):
+    """A survivor queue that is far too small must be detected on the device and answered by the monolithic
+    kernel -- same result, no silent truncation."""
+    import torch
+    from pigo_amd import batch
+    monkeypatch.setenv("PIGO_QUEUE_DIV", "100000")  # queue capacity = the 4096-entry floor
+    fresh = core.NewPigo(0).Unpack(synth.facefinder_bytes())
+    rows, cols = 540, 960
+    f = synth.make_frames("noise", 2, rows, cols, seed=5)
+    d_frames = torch.from_numpy(f).to("cuda:0")
+    plan = batch.ScanPlan(fresh, rows, cols, max_frames=2, det_cap=256)
+    assert plan.info().queue_capacity <= 8192
+    dets, counts = plan.alloc_outputs(2)
+    plan.run(d_frames, dets, counts)
+    torch.cuda.synchronize()
+    with pytest.raises(core.PigoError):
+        plan.status()  # overflow reported ...
+    plan.run(d_frames, dets, counts, sync=True)  # ... and the sync wrapper re-runs with the fallback
+    got = batch.dets_to_numpy(dets, counts)
+    for k in range(2):
+        assert_same_dets(got[k], orc.run_cascade(f[k], rows, cols, cols, 20, 1000, 0.1, 1.1, 0.0), f"fallback frame {k}", Q_TOL_RAW)
+
+
+def test_detection_capacity_is_reported(pg):
+    f = synth.make_frames("faces", 1, 1080, 1920, seed=1234)[0]
+    L = core.load_library()
+    import ctypes as C
+    out = np.zeros(4, dtype=core.DET_DTYPE)
+    n = C.c_int(0)
+    pix = np.ascontiguousarray(f).ravel()
+    st = L.pigo_run_cascade(pg._need(), pix.ctypes.data, pix.size, 1080, 1920, 1920, 20, 1000, 0.1, 1.1, 0.0, out.ctypes.data, 4, C.byref(n))
+    assert st == core.ERR_CAPACITY and n.value > 4
+
+
+def test_4k_config5_variants_agree_and_match_oracle(pg, orc):
+    """BASELINE config 5: 3840x2160, MinSize 20, MaxSize 2000, shift 0.05, scale 1.05 -> 113,382,193 windows."""
+    import torch
+    from pigo_amd import batch
+    f = synth.make_frames("faces", 1, 2160, 3840, seed=1234)
+    d_frames = torch.from_numpy(f).to("cuda:0")
+    res = {}
+    for variant in (1, 0):
+        plan = batch.ScanPlan(pg, 2160, 3840, MinSize=20, MaxSize=2000, ShiftFactor=0.05, ScaleFactor=1.05, max_frames=1, det_cap=32768)
+        plan.set_variant(variant)
+        assert plan.info().windows_per_frame == 113382193 and plan.info().n_scales == 96
+        dets, counts = plan.alloc_outputs(1)
+        plan.run(d_frames, dets, counts, sync=True)
+        res[variant] = batch.dets_to_numpy(dets, counts, 0)
+    assert_same_dets(res[1], res[0], "4K v1 vs v0", Q_TOL_RAW)
+    want = orc.run_cascade(f[0], 2160, 3840, 3840, 20, 2000, 0.05, 1.05, 0.0)  # ~15 s of CPU
+    assert_same_dets(res[1], want, "4K vs oracle", Q_TOL_RAW)
+    wc, ties = orc.cluster_detections(want.copy(), 0.2, want_ties=True)
+    got = pg.ClusterDetections(res[1].copy(), 0.2)
+    assert_same_dets(got, wc, f"4K clusters (ties={ties})", Q_TOL_RAW)
