@@ -104,15 +104,18 @@ typedef struct {
     int32_t n_ladder;          /* all rungs, including the ones larger than the image */
     int32_t tiles_per_frame;   /* workgroups per frame of the head kernel */
     int32_t n_head_trees;      /* trees evaluated by the dense head kernel */
-    int32_t variant;           /* 0 = monolithic scan, 1 = head + compacted tail */
+    int32_t variant;           /* 0 = monolithic scan, 1 = head + survivor-queue tail, 2 = whole cascade per LDS tile */
     int32_t max_frames, det_cap;
     int64_t queue_capacity;    /* survivor-queue entries shared by the batch */
     int64_t workspace_bytes;
 } pigo_plan_info_t;
 pigo_status pigo_plan_info(const pigo_plan *p, pigo_plan_info_t *info);
 
-/* Selects the scan implementation for this plan: 0 = monolithic lane-per-window kernel (also the
- * overflow fallback), 1 = dense head + compacted tail (default when the cascade has depth 6). */
+/* Selects the scan implementation for this plan:
+ *   0 = monolithic lane-per-window kernel (any tree depth; also variant 1's overflow fallback),
+ *   1 = dense head kernel + survivor queue + tail kernel, pixels gathered from global memory,
+ *   2 = one workgroup takes a tile of windows through the whole cascade out of an LDS copy of the tile's
+ *       pixels (default when the cascade has depth 6). */
 pigo_status pigo_plan_set_variant(pigo_plan *p, int variant);
 
 /* Asynchronous scan of `nframes` (<= max_frames) device-resident frames.  `d_frames` points to

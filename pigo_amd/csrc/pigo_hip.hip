@@ -130,6 +130,18 @@ struct pigo_plan {
     DevBuf<ScaleDesc> d_scales;
     DevBuf<uint32_t> d_tiles;
     DevBuf<int2> d_tab;
+    // variant 2 (k_scan_tile): tile classes = (geometry, LDS footprint bucket), one launch per class
+    struct TileClass {
+        int tw_log2, th, nwin;
+        bool lds;
+        uint32_t tile0, ntiles;
+        size_t dyn_lds;
+    };
+    std::vector<TileClass> classes;
+    std::vector<uint2> tiles2;
+    DevBuf<uint2> d_tiles2;
+    DevBuf<uint32_t> d_tabp;
+    bool tile_ok = false;
     DevBuf<QEntry> d_queue;
     DevBuf<uint32_t> d_qcount;
     DevBuf<RawDet> d_raw;
@@ -149,7 +161,7 @@ struct pigo_plan {
     }
     size_t workspace_bytes() const
     {
-        return d_scales.bytes() + d_tiles.bytes() + d_tab.bytes() + d_queue.bytes() + d_qcount.bytes() + d_raw.bytes() + d_flags.bytes() +
+        return d_scales.bytes() + d_tiles.bytes() + d_tiles2.bytes() + d_tabp.bytes() + d_tab.bytes() + d_queue.bytes() + d_qcount.bytes() + d_raw.bytes() + d_flags.bytes() +
                d_mq.bytes();
     }
 };
@@ -345,6 +357,149 @@ void build_stages(pigo_plan &p, int head_stages_wanted)
     }
 }
 
+int env_int(const char *name, int dflt);
+
+// Stages (compaction points) and LDS table windows of k_scan_tile.  A stage never spans more than kTabTrees
+// trees, so the tables of the trees it walks are always resident.
+bool build_tile_stages(pigo_plan &p)
+{
+    const pigo_cascade &c = *p.c;
+    const int nt = (int)c.ntrees;
+    if (nt == 0 || c.depth != 6) return false;
+    float lo = c.thr[0];
+    for (int i = 0; i < nt; ++i) lo = std::min(lo, c.thr[i]);
+    std::vector<int> ends;
+    int begin = 0;
+    for (int i = 0; i < nt; ++i) {
+        if (c.thr[i] > lo || i == nt - 1) {
+            while (i - begin + 1 > kTabTrees) {  // split over-long stages
+                ends.push_back(begin + kTabTrees - 1);
+                begin += kTabTrees;
+            }
+            ends.push_back(i);
+            begin = i + 1;
+        }
+    }
+    while ((int)ends.size() > kMaxStages) {  // too many compaction points: merge neighbours that still fit
+        std::vector<int> m;
+        int b = 0;
+        bool merged = false;
+        for (size_t i = 0; i < ends.size(); ++i) {
+            if (i + 1 < ends.size() && ends[i + 1] - b + 1 <= kTabTrees) {
+                merged = true;
+                ++i;
+            }
+            m.push_back(ends[i]);
+            b = ends[i] + 1;
+        }
+        if (!merged) return false;
+        ends.swap(m);
+    }
+    ScanArgs &a = p.args;
+    a.n_stages = (int)ends.size();
+    int hi = 0;  // trees [.., hi) are resident
+    for (int st = 0; st < a.n_stages; ++st) {
+        const int t0 = st == 0 ? 0 : ends[st - 1] + 1;
+        a.st_end[st] = (int16_t)ends[st];
+        a.st_load_hi[st] = 0;
+        if (ends[st] >= hi) {
+            int last = st;
+            while (last + 1 < a.n_stages && ends[last + 1] - t0 + 1 <= kTabTrees) ++last;
+            hi = ends[last] + 1;
+            a.st_load_hi[st] = (int16_t)hi;
+        }
+    }
+    return true;
+}
+
+struct TileRule {
+    int tw_log2, th;
+    long long max_pix;
+};
+
+// Per-rung tile geometry: the first rule whose LDS pixel footprint fits wins; rungs that fit none (or frames
+// that cannot be copied as aligned dwords, or the rotated scan) read pixels from global memory.
+void build_tile_classes(pigo_plan &p)
+{
+    std::vector<TileRule> rules;
+    const char *env = getenv("PIGO_TILE_RULES");
+    std::string spec = env && *env ? env : "6,32,16384;6,16,24576;6,8,36864;6,4,57344;5,4,112640";
+    {
+        size_t pos = 0;
+        while (pos < spec.size()) {
+            size_t end = spec.find(';', pos);
+            if (end == std::string::npos) end = spec.size();
+            TileRule r{};
+            if (sscanf(spec.substr(pos, end - pos).c_str(), "%d,%d,%lld", &r.tw_log2, &r.th, &r.max_pix) == 3 && r.tw_log2 >= 5 && r.tw_log2 <= 6 &&
+                r.th >= 1 && ((1 << r.tw_log2) * r.th) % kThreads == 0 && (1 << r.tw_log2) * r.th <= 4096)
+                rules.push_back(r);
+            pos = end + 1;
+        }
+    }
+    const bool lds_allowed = !p.rot && (p.key.dim % 4 == 0) && env_int("PIGO_LDS_TILES", 1) != 0;
+    const int g_tw_log2 = 6, g_th = env_int("PIGO_GLOBAL_TH", 16);
+    const size_t static_slack = 1024;
+    const size_t buckets[] = {36u << 10, 48u << 10, 64u << 10, 80u << 10, 104u << 10, 128u << 10, (160u << 10) - static_slack};
+    struct Pick {
+        int tw_log2, th;
+        bool lds;
+        size_t dyn;
+        int bucket;
+    };
+    std::vector<Pick> picks(p.scales.size());
+    for (size_t k = 0; k < p.scales.size(); ++k) {
+        ScaleDesc &sd = p.scales[k];
+        const int up = (sd.s + 1) / 2, down = (127 * sd.s) >> 8;
+        sd.up = up;
+        sd.pitch = 0;
+        Pick pk{g_tw_log2, g_th, false, 0, 0};
+        if (lds_allowed) {
+            for (const TileRule &r : rules) {
+                const int tw = 1 << r.tw_log2;
+                long long w = (long long)(tw - 1) * sd.step + up + down + 1 + 3;
+                long long pitch = (w + 3) / 4 * 4;
+                if ((pitch / 4) % 2 == 0) pitch += 4;  // odd dword pitch: consecutive rows start on different banks
+                const long long ph = (long long)(r.th - 1) * sd.step + up + down + 1;
+                const long long pix = pitch * ph;
+                if (pix > r.max_pix) continue;
+                if ((long long)up * pitch + up > 32767) continue;  // offsets must fit the packed int16 table
+                sd.pitch = (int32_t)pitch;
+                pk = Pick{r.tw_log2, r.th, true, (size_t)((pix + 15) / 16 * 16), 0};
+                break;
+            }
+        }
+        const size_t nwin = (size_t)(1 << pk.tw_log2) * pk.th;
+        pk.dyn += (size_t)kTabTrees * 64 * (pk.lds ? 4 : 8) + 12 * nwin;
+        pk.bucket = (int)(sizeof(buckets) / sizeof(buckets[0])) - 1;
+        for (int b = 0; b < (int)(sizeof(buckets) / sizeof(buckets[0])); ++b)
+            if (pk.dyn <= buckets[b]) {
+                pk.bucket = b;
+                break;
+            }
+        picks[k] = pk;
+    }
+    p.classes.clear();
+    p.tiles2.clear();
+    std::vector<char> done(p.scales.size(), 0);
+    for (size_t k = 0; k < p.scales.size(); ++k) {
+        if (done[k]) continue;
+        pigo_plan::TileClass cls{picks[k].tw_log2, picks[k].th, (1 << picks[k].tw_log2) * picks[k].th, picks[k].lds, (uint32_t)p.tiles2.size(), 0, 0};
+        for (size_t j = k; j < p.scales.size(); ++j) {
+            const Pick &q = picks[j];
+            if (done[j] || q.tw_log2 != cls.tw_log2 || q.th != cls.th || q.lds != cls.lds || q.bucket != picks[k].bucket) continue;
+            done[j] = 1;
+            cls.dyn_lds = std::max(cls.dyn_lds, q.dyn);
+            const ScaleDesc &sd = p.scales[j];
+            const int tw = 1 << cls.tw_log2;
+            const int tys = (sd.nr + cls.th - 1) / cls.th, txs = (sd.nc + tw - 1) / tw;
+            for (int ty = 0; ty < tys; ++ty)
+                for (int tx = 0; tx < txs; ++tx) p.tiles2.push_back(make_uint2((unsigned)j, ((unsigned)ty << 16) | (unsigned)tx));
+        }
+        cls.ntiles = (uint32_t)p.tiles2.size() - cls.tile0;
+        p.classes.push_back(cls);
+    }
+}
+
 int env_int(const char *name, int dflt)
 {
     const char *v = getenv(name);
@@ -397,6 +552,9 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     pigo_status st = build_ladder(*p);
     if (st != PIGO_OK) return st;
 
+    p->tile_ok = build_tile_stages(*p);
+    build_tile_classes(*p);  // also fills ScaleDesc::pitch / up
+
     HIP_TRY(hipSetDevice(c->device));
     const int nscales = (int)p->scales.size();
     HIP_TRY(p->d_scales.alloc(nscales));
@@ -416,6 +574,20 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }
+    if (p->tile_ok && nscales) {
+        HIP_TRY(p->d_tiles2.alloc(p->tiles2.size()));
+        HIP_TRY(hipMemcpy(p->d_tiles2.p, p->tiles2.data(), p->tiles2.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        HIP_TRY(p->d_tabp.alloc((size_t)nscales * c->ntrees * 64));
+        const size_t n = (size_t)nscales * c->ntrees * 64;
+        k_build_tabp<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256>>>(c->d_codes.p, p->d_scales.p, p->d_tabp.p, nscales, (int)c->ntrees);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        const int max_dyn = (160 << 10) - 1024;
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+    }
     st = plan_alloc_batch(*p, max_frames, det_cap);
     if (st != PIGO_OK) return st;
 
@@ -423,6 +595,8 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.scales = p->d_scales.p;
     a.tiles = p->d_tiles.p;
     a.tab = p->d_tab.p;
+    a.tiles2 = p->d_tiles2.p;
+    a.tabp = p->d_tabp.p;
     a.leaf = c->d_leaf.p;
     a.thr = c->d_thr.p;
     a.queue = p->d_queue.p;
@@ -439,8 +613,9 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.qcap = (uint32_t)p->qcap;
     a.det_cap = det_cap;
     build_stages(*p, env_int("PIGO_HEAD_STAGES", kMaxHeadStages));
-    p->variant = (c->depth == 6 && c->ntrees > 0) ? env_int("PIGO_SCAN_VARIANT", 1) : 0;
-    if (p->variant != 0 && !(c->depth == 6 && c->ntrees > 0)) p->variant = 0;
+    p->variant = (c->depth == 6 && c->ntrees > 0) ? env_int("PIGO_SCAN_VARIANT", p->tile_ok ? 2 : 1) : 0;
+    if (p->variant == 2 && !p->tile_ok) p->variant = 1;
+    if (p->variant < 0 || p->variant > 2) p->variant = 0;
     out = std::move(p);
     return PIGO_OK;
 }
@@ -449,7 +624,27 @@ template <bool ROT, bool GUARD, class Mark>
 void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t s, Mark &mark)
 {
     const uint32_t nb = (uint32_t)a.nframes * (uint32_t)a.ntiles;
-    if (variant == 1) {
+    if (variant == 2) {
+        for (const pigo_plan::TileClass &cls : p.classes) {
+            if (cls.ntiles == 0) continue;
+            ScanArgs ca = a;
+            ca.cls_tile0 = cls.tile0;
+            ca.cls_ntiles = cls.ntiles;
+            ca.tw_log2 = cls.tw_log2;
+            ca.th = cls.th;
+            ca.nwin = cls.nwin;
+            const uint32_t grid = (uint32_t)a.nframes * cls.ntiles;
+            mark(cls.lds ? "scan_tile_lds" : "scan_tile_glb");
+            if constexpr (!ROT) {
+                if (cls.lds)
+                    k_scan_tile<false, false, true><<<grid, kThreads, cls.dyn_lds, s>>>(ca);
+                else
+                    k_scan_tile<false, false, false><<<grid, kThreads, cls.dyn_lds, s>>>(ca);
+            } else {
+                k_scan_tile<true, GUARD, false><<<grid, kThreads, cls.dyn_lds, s>>>(ca);
+            }
+        }
+    } else if (variant == 1) {
         mark("scan_head");
         k_scan_head<ROT, GUARD><<<nb, kThreads, 0, s>>>(a);
         if (a.n_tail_stages > 0) {
@@ -558,8 +753,9 @@ extern "C" pigo_status pigo_plan_info(const pigo_plan *p, pigo_plan_info_t *info
 extern "C" pigo_status pigo_plan_set_variant(pigo_plan *p, int variant)
 {
     if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
-    if (variant != 0 && variant != 1) return fail(PIGO_ERR_PARAM, "variant must be 0 or 1");
-    if (variant == 1 && !(p->c->depth == 6 && p->c->ntrees > 0)) return fail(PIGO_ERR_PARAM, "variant 1 needs a depth-6 cascade");
+    if (variant < 0 || variant > 2) return fail(PIGO_ERR_PARAM, "variant must be 0, 1 or 2");
+    if (variant >= 1 && !(p->c->depth == 6 && p->c->ntrees > 0)) return fail(PIGO_ERR_PARAM, "variants 1 and 2 need a depth-6 cascade");
+    if (variant == 2 && !p->tile_ok) return fail(PIGO_ERR_PARAM, "variant 2 not available for this cascade");
     p->variant = variant;
     return PIGO_OK;
 }

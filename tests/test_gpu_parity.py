@@ -48,7 +48,7 @@ def test_unpack_tables_match_oracle(pg, orc):
 # ---- RunCascade + ClusterDetections against the goldens (both scan variants) -----------------------------------
 
 
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("variant", [2, 1, 0])
 def test_golden_cases(pg, golden, variant, monkeypatch):
     monkeypatch.setenv("PIGO_SCAN_VARIANT", str(variant))
     fresh = core.NewPigo(0).Unpack(synth.facefinder_bytes())  # new handle: plans are cached per handle
@@ -72,7 +72,7 @@ def test_reference_test_invariants(pg, gray):
 # ---- seeded sweeps against the oracle -------------------------------------------------------------------------
 
 
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("variant", [2, 1, 0])
 def test_random_parameter_sweep(orc, variant, monkeypatch):
     monkeypatch.setenv("PIGO_SCAN_VARIANT", str(variant))
     fresh = core.NewPigo(0).Unpack(synth.facefinder_bytes())
@@ -184,7 +184,7 @@ def test_batch_api_matches_single_frame_and_is_order_stable(pg, orc):
     dev = torch.device("cuda", 0)
     d_frames = torch.from_numpy(frames).to(dev)
     want = [orc.run_cascade(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1, 0.0) for f in range(n)]
-    for variant in (1, 0):
+    for variant in (2, 1, 0):
         plan = batch.ScanPlan(pg, rows, cols, MinSize=20, MaxSize=1000, ShiftFactor=0.1, ScaleFactor=1.1, max_frames=n, det_cap=512)
         plan.set_variant(variant)
         dets, counts = plan.alloc_outputs(n)
@@ -211,12 +211,32 @@ def test_batch_api_matches_single_frame_and_is_order_stable(pg, orc):
                 assert_same_dets(srt[f], w, f"batch sorted frame {f}", Q_TOL_RAW)
 
 
+@pytest.mark.parametrize("rules", ["5,8,20480", "6,32,40000;6,4,60000", "6,4,4096"])
+def test_tile_geometry_rules(orc, rules, monkeypatch):
+    """Variant 2 with unusual tile geometries (32-wide tiles, 2048-window tiles, almost everything on the
+    global-memory class): the result may not depend on how the index space is tiled."""
+    monkeypatch.setenv("PIGO_TILE_RULES", rules)
+    monkeypatch.setenv("PIGO_SCAN_VARIANT", "2")
+    fresh = core.NewPigo(0).Unpack(synth.facefinder_bytes())
+    for k, (rows, cols) in enumerate(((400, 320), (270, 480))):
+        img = synth.sample_gray() if k == 0 else synth.syn_faces(rows, cols, seed=8, frame_index=k)
+        want = orc.run_cascade(img, rows, cols, cols, 20, 1000, 0.1, 1.1, 0.0)
+        got = fresh.RunCascade(_cp(img, rows, cols, cols, 20, 1000, 0.1, 1.1), 0.0)
+        assert_same_dets(got, want, f"rules {rules} {rows}x{cols}", Q_TOL_RAW)
+    # dim not a multiple of 4: the LDS path is not eligible, every rung takes the global-memory class
+    img = np.zeros((200, 301), dtype=np.uint8)
+    img[:, :300] = synth.syn_faces(200, 300, seed=9)
+    want = orc.run_cascade(img, 200, 300, 301, 20, 1000, 0.1, 1.1, 0.0)
+    assert_same_dets(fresh.RunCascade(_cp(img, 200, 300, 301, 20, 1000, 0.1, 1.1), 0.0), want, "dim 301", Q_TOL_RAW)
+
+
 def test_queue_overflow_falls_back_to_monolithic(orc, monkeypatch):
     """A survivor queue that is far too small must be detected on the device and answered by the monolithic
     kernel -- same result, no silent truncation."""
     import torch
     from pigo_amd import batch
     monkeypatch.setenv("PIGO_QUEUE_DIV", "100000")  # queue capacity = the 4096-entry floor
+    monkeypatch.setenv("PIGO_SCAN_VARIANT", "1")     # the survivor queue belongs to variant 1
     fresh = core.NewPigo(0).Unpack(synth.facefinder_bytes())
     rows, cols = 540, 960
     f = synth.make_frames("noise", 2, rows, cols, seed=5)
@@ -252,7 +272,7 @@ def test_4k_config5_variants_agree_and_match_oracle(pg, orc):
     f = synth.make_frames("faces", 1, 2160, 3840, seed=1234)
     d_frames = torch.from_numpy(f).to("cuda:0")
     res = {}
-    for variant in (1, 0):
+    for variant in (2, 1, 0):
         plan = batch.ScanPlan(pg, 2160, 3840, MinSize=20, MaxSize=2000, ShiftFactor=0.05, ScaleFactor=1.05, max_frames=1, det_cap=32768)
         plan.set_variant(variant)
         assert plan.info().windows_per_frame == 113382193 and plan.info().n_scales == 96
@@ -260,6 +280,7 @@ def test_4k_config5_variants_agree_and_match_oracle(pg, orc):
         plan.run(d_frames, dets, counts, sync=True)
         res[variant] = batch.dets_to_numpy(dets, counts, 0)
     assert_same_dets(res[1], res[0], "4K v1 vs v0", Q_TOL_RAW)
+    assert_same_dets(res[2], res[0], "4K v2 vs v0", Q_TOL_RAW)
     want = orc.run_cascade(f[0], 2160, 3840, 3840, 20, 2000, 0.05, 1.05, 0.0)  # ~15 s of CPU
     assert_same_dets(res[1], want, "4K vs oracle", Q_TOL_RAW)
     wc, ties = orc.cluster_detections(want.copy(), 0.2, want_ties=True)
