@@ -171,6 +171,11 @@ def main():
             ktimes[name] = ktimes.get(name, 0.0) + ms / reps
     plan.set_profiling(False)
     survivors = plan.last_queue_count()
+    if os.environ.get("PIGO_DEBUG_STATS"):
+        st = plan.debug_stats()
+        tiles = max(st[4], 1)
+        print("debug_stats (cycles per tile): copy %.0f stage0 %.0f dense %.0f late %.0f | late windows/tile %.1f late trees/tile %.1f tiles %d" %
+              (st[0] / tiles, st[1] / tiles, st[2] / tiles, st[3] / tiles, st[5] / tiles, st[6] / tiles, st[4]), file=sys.stderr)
     ndet = int(counts.sum().item())
     cev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     cluster_ms = None

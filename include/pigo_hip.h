@@ -150,6 +150,13 @@ pigo_status pigo_plan_run_sync(pigo_plan *p, const uint8_t *d_frames, size_t fra
 pigo_status pigo_plan_set_profiling(pigo_plan *p, int on);
 int pigo_plan_last_timings(pigo_plan *p, const char **names, float *ms, int cap);
 
+/* Debug only (plans created with PIGO_DEBUG_STATS=1 in the environment): accumulated shader-clock totals of
+ * k_scan_tile's phases since the last call -- [0] tile/table copies, [1] stage 0, [2] later dense stages,
+ * [3] late mode, [4] tiles, [5] windows entering late mode, [6] trees walked in late mode.  Zeros otherwise. */
+pigo_status pigo_plan_debug_stats(pigo_plan *p, uint64_t *out, int n);
+/* Debug only: raw per-iteration trace of late mode for 16 tiles (n >= 4096 words). */
+pigo_status pigo_plan_debug_trace(pigo_plan *p, uint64_t *out, int n);
+
 /* Device statistics of the most recent run (valid after synchronising): survivor-queue entries. */
 pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n);
 

@@ -106,6 +106,11 @@ class ScanPlan:
         k = self.L.pigo_plan_last_timings(self._h, names, ms, 16)
         return [(names[i].decode(), float(ms[i])) for i in range(k)]
 
+    def debug_stats(self):
+        out = (C.c_uint64 * 16)()
+        core.check(self.L.pigo_plan_debug_stats(self._h, out, 16))
+        return [int(v) for v in out]
+
     def last_queue_count(self):
         n = C.c_int64(0)
         core.check(self.L.pigo_plan_last_queue_count(self._h, C.byref(n)))

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "pigo_last_error", "pigo_device_count", "pigo_cascade_create", "pigo_cascade_info", "pigo_cascade_tables", "pigo_cascade_destroy",
     "pigo_run_cascade", "pigo_cluster_detections", "pigo_sort_by_q", "pigo_plan_create", "pigo_plan_destroy", "pigo_plan_info",
     "pigo_plan_set_variant", "pigo_plan_run", "pigo_plan_cluster", "pigo_plan_status", "pigo_plan_run_sync", "pigo_plan_set_profiling",
-    "pigo_plan_last_timings", "pigo_plan_last_queue_count",
+    "pigo_plan_last_timings", "pigo_plan_last_queue_count", "pigo_plan_debug_stats", "pigo_plan_debug_trace",
 ]
 
 _lib = None
@@ -90,6 +90,8 @@ def load_library():
     L.pigo_plan_set_profiling.argtypes = [vp, i32]
     L.pigo_plan_last_timings.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), i32]
     L.pigo_plan_last_queue_count.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.pigo_plan_debug_stats.argtypes = [vp, C.POINTER(C.c_uint64), i32]
+    L.pigo_plan_debug_trace.argtypes = [vp, C.POINTER(C.c_uint64), i32]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("pigo_device_count", "pigo_plan_last_timings"):

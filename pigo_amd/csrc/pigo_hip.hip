@@ -142,11 +142,13 @@ struct pigo_plan {
     DevBuf<uint2> d_tiles2;
     DevBuf<uint32_t> d_tabp;
     bool tile_ok = false;
+    size_t deep_lds = 0;                 // dynamic LDS of k_tail_deep
     DevBuf<QEntry> d_queue;
     DevBuf<uint32_t> d_qcount;
     DevBuf<RawDet> d_raw;
     DevBuf<int32_t> d_flags;
     DevBuf<float> d_mq;
+    DevBuf<unsigned long long> d_stats;
     long long qcap = 0;
     // profiling
     bool profiling = false;
@@ -368,13 +370,19 @@ bool build_tile_stages(pigo_plan &p)
     if (nt == 0 || c.depth != 6) return false;
     float lo = c.thr[0];
     for (int i = 0; i < nt; ++i) lo = std::min(lo, c.thr[i]);
+    ScanArgs &a = p.args;
+    a.nh_lds = std::min(nt, std::max(1, env_int("PIGO_NH_LDS", 28)));
+    a.nh_glb = std::min(nt, std::max(1, env_int("PIGO_NH_GLB", 18)));
+    a.deep_lo = std::min(a.nh_lds, a.nh_glb);
+    a.tab_trees = std::min(kTabTrees, std::max(std::max(a.nh_lds, a.nh_glb), 8));
+    const int cap = a.tab_trees;
     std::vector<int> ends;
     int begin = 0;
     for (int i = 0; i < nt; ++i) {
         if (c.thr[i] > lo || i == nt - 1) {
-            while (i - begin + 1 > kTabTrees) {  // split over-long stages
-                ends.push_back(begin + kTabTrees - 1);
-                begin += kTabTrees;
+            while (i - begin + 1 > cap) {  // split over-long stages
+                ends.push_back(begin + cap - 1);
+                begin += cap;
             }
             ends.push_back(i);
             begin = i + 1;
@@ -385,7 +393,7 @@ bool build_tile_stages(pigo_plan &p)
         int b = 0;
         bool merged = false;
         for (size_t i = 0; i < ends.size(); ++i) {
-            if (i + 1 < ends.size() && ends[i + 1] - b + 1 <= kTabTrees) {
+            if (i + 1 < ends.size() && ends[i + 1] - b + 1 <= cap) {
                 merged = true;
                 ++i;
             }
@@ -395,8 +403,9 @@ bool build_tile_stages(pigo_plan &p)
         if (!merged) return false;
         ends.swap(m);
     }
-    ScanArgs &a = p.args;
     a.n_stages = (int)ends.size();
+    p.deep_lds = (size_t)(nt - a.deep_lo) * kCodeStride * 4 + (size_t)kDeepWaves * kPatchBytes;
+    if (p.deep_lds > (size_t)(160 << 10) - 1024) return false;  // the deep trees' codes must fit one CU's LDS
     int hi = 0;  // trees [.., hi) are resident
     for (int st = 0; st < a.n_stages; ++st) {
         const int t0 = st == 0 ? 0 : ends[st - 1] + 1;
@@ -404,7 +413,7 @@ bool build_tile_stages(pigo_plan &p)
         a.st_load_hi[st] = 0;
         if (ends[st] >= hi) {
             int last = st;
-            while (last + 1 < a.n_stages && ends[last + 1] - t0 + 1 <= kTabTrees) ++last;
+            while (last + 1 < a.n_stages && ends[last + 1] - t0 + 1 <= cap) ++last;
             hi = ends[last] + 1;
             a.st_load_hi[st] = (int16_t)hi;
         }
@@ -423,7 +432,7 @@ void build_tile_classes(pigo_plan &p)
 {
     std::vector<TileRule> rules;
     const char *env = getenv("PIGO_TILE_RULES");
-    std::string spec = env && *env ? env : "6,32,16384;6,16,24576;6,8,36864;6,4,57344;5,4,112640";
+    std::string spec = env && *env ? env : "6,32,16384;6,16,24576;6,8,36864";
     {
         size_t pos = 0;
         while (pos < spec.size()) {
@@ -469,7 +478,8 @@ void build_tile_classes(pigo_plan &p)
             }
         }
         const size_t nwin = (size_t)(1 << pk.tw_log2) * pk.th;
-        pk.dyn += (size_t)kTabTrees * 64 * (pk.lds ? 4 : 8) + 12 * nwin;
+        const size_t qbytes = 6 * (nwin + nwin / (p.rot ? 1 : 2));
+        pk.dyn += (size_t)p.args.tab_trees * 64 * (pk.lds ? 4 : 8) + qbytes + (qbytes >= (size_t)64 * (kWaves * kLateTrees + 1) * 4 ? 0 : (size_t)64 * (kWaves * kLateTrees + 1) * 4);
         pk.bucket = (int)(sizeof(buckets) / sizeof(buckets[0])) - 1;
         for (int b = 0; b < (int)(sizeof(buckets) / sizeof(buckets[0])); ++b)
             if (pk.dyn <= buckets[b]) {
@@ -534,6 +544,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     if (!std::isfinite(key.shift) || !std::isfinite(key.scale) || !std::isfinite(key.angle))
         return fail(PIGO_ERR_PARAM, "non-finite shift/scale/angle");
     if (max_frames < 1 || det_cap < 1) return fail(PIGO_ERR_PARAM, "max_frames and det_cap must be >= 1");
+    if (max_frames >= (1 << 21)) return fail(PIGO_ERR_PARAM, "max_frames must be below 2^21");
     if ((long long)max_frames * det_cap > (1LL << 31)) return fail(PIGO_ERR_PARAM, "max_frames * det_cap too large");
 
     std::unique_ptr<pigo_plan> p(new (std::nothrow) pigo_plan);
@@ -587,6 +598,9 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
     }
     st = plan_alloc_batch(*p, max_frames, det_cap);
     if (st != PIGO_OK) return st;
@@ -597,6 +611,17 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.tab = p->d_tab.p;
     a.tiles2 = p->d_tiles2.p;
     a.tabp = p->d_tabp.p;
+    a.codes = c->d_codes.p;
+    a.late_waves = std::max(1, std::min(kWaves, env_int("PIGO_LATE_WAVES", kWaves)));
+    a.qb_div = p->rot ? 1 : 2;
+    a.stats = nullptr;
+    if (env_int("PIGO_DEBUG_STATS", 0)) {
+        HIP_TRY(p->d_stats.alloc(65536 * 8 + 16 * 256));
+        HIP_TRY(hipMemset(p->d_stats.p, 0, (65536 * 8 + 16 * 256) * 8));
+        a.stats = p->d_stats.p;
+    }
+    a.qcos = kQCos[p->angle_idx];
+    a.qsin = kQSin[p->angle_idx];
     a.leaf = c->d_leaf.p;
     a.thr = c->d_thr.p;
     a.queue = p->d_queue.p;
@@ -628,6 +653,7 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
         for (const pigo_plan::TileClass &cls : p.classes) {
             if (cls.ntiles == 0) continue;
             ScanArgs ca = a;
+            ca.qcap = (uint32_t)std::min<long long>(p.qcap * (long long)p.max_frames, 0xffffffffLL);
             ca.cls_tile0 = cls.tile0;
             ca.cls_ntiles = cls.ntiles;
             ca.tw_log2 = cls.tw_log2;
@@ -643,6 +669,12 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             } else {
                 k_scan_tile<true, GUARD, false><<<grid, kThreads, cls.dyn_lds, s>>>(ca);
             }
+        }
+        if (a.deep_lo < a.ntrees) {
+            mark("tail_deep");
+            ScanArgs ta = a;
+            ta.qcap = (uint32_t)std::min<long long>(p.qcap * (long long)p.max_frames, 0xffffffffLL);
+            k_tail_deep<ROT, GUARD><<<256, kDeepThreads, p.deep_lds, s>>>(ta);
         }
     } else if (variant == 1) {
         mark("scan_head");
@@ -678,7 +710,7 @@ pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame
     a.nframes = nframes;
     a.counts = d_counts;
     a.tail_wgs = std::max(8, std::min(256, 2048 / nframes));
-    if (variant == 1) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)nframes * 4, s));
+    if (variant >= 1) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)nframes * 4, s));
 
     size_t ev = 0;
     auto mark = [&](const char *name) {
@@ -788,7 +820,7 @@ extern "C" pigo_status pigo_plan_run_sync(pigo_plan *p, const uint8_t *d_frames,
     if (st != PIGO_OK) return st;
     HIP_TRY(hipStreamSynchronize(s));
     st = pigo_plan_status(p);
-    if (st == PIGO_ERR_CAPACITY && p->variant == 1) {  // pathological frame: more survivors than the queue holds
+    if (st == PIGO_ERR_CAPACITY && p->variant >= 1) {  // pathological frame: more survivors than the queue holds
         st = plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, s, 0);
         if (st != PIGO_OK) return st;
         HIP_TRY(hipStreamSynchronize(s));
@@ -817,6 +849,28 @@ extern "C" int pigo_plan_last_timings(pigo_plan *p, const char **names, float *m
         ++n;
     }
     return n;
+}
+
+extern "C" pigo_status pigo_plan_debug_trace(pigo_plan *p, uint64_t *out, int n)
+{
+    if (!p || !out || n < 16 * 256 || !p->d_stats.p) return fail(PIGO_ERR_PARAM, "bad argument");
+    HIP_TRY(hipSetDevice(p->c->device));
+    HIP_TRY(hipMemcpy(out, p->d_stats.p + 65536 * 8, 16 * 256 * 8, hipMemcpyDeviceToHost));
+    return PIGO_OK;
+}
+
+extern "C" pigo_status pigo_plan_debug_stats(pigo_plan *p, uint64_t *out, int n)
+{
+    if (!p || !out || n < 1) return fail(PIGO_ERR_PARAM, "bad argument");
+    memset(out, 0, (size_t)n * 8);
+    if (!p->d_stats.p) return PIGO_OK;
+    HIP_TRY(hipSetDevice(p->c->device));
+    std::vector<unsigned long long> h(65536 * 8);
+    HIP_TRY(hipMemcpy(h.data(), p->d_stats.p, h.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(p->d_stats.p, 0, h.size() * 8));
+    for (size_t b = 0; b < 65536; ++b)
+        for (int k = 0; k < 8 && k < n; ++k) out[k] += h[b * 8 + k];
+    return PIGO_OK;
 }
 
 extern "C" pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n)
