@@ -77,15 +77,20 @@ def cpu_baseline(args, frames, windows_per_frame):
     for i in range(n1):
         scan(frames[i % len(frames)])
     t1 = (time.perf_counter() - t) / n1
-    # all cores: ctypes releases the GIL during the C call
-    per_thread = args.cpu_frames or max(1, int(8.0 / max(t1, 1e-3)))
-    threads = [threading.Thread(target=lambda k=k: [scan(frames[(k + j) % len(frames)]) for j in range(per_thread)]) for k in range(ncores)]
-    t = time.perf_counter()
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    tall = time.perf_counter() - t
+    # all cores: ctypes releases the GIL during the C call.  Calibrate with one frame per thread, then size the timed
+    # sample to ~10 s so that the whole leg stays within ~25 s of CPU wall time.
+    def run_all(per_thread):
+        threads = [threading.Thread(target=lambda k=k: [scan(frames[(k + j) % len(frames)]) for j in range(per_thread)]) for k in range(ncores)]
+        t = time.perf_counter()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        return time.perf_counter() - t
+
+    tcal = run_all(1)
+    per_thread = args.cpu_frames or max(1, min(8, int(10.0 / max(tcal, 1e-3))))
+    tall = run_all(per_thread)
     fps_all = ncores * per_thread / tall
     return {
         "value": round(fps_all * windows_per_frame / 1e6, 3), "unit": "Mwindows/s", "cores": ncores, "kind": "port",

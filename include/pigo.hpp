@@ -1,0 +1,144 @@
+// pigo.hpp -- header-only C++17 mirror of the reference's Go API (package github.com/esimov/pigo/core) over the
+// C ABI of libpigo_hip.so (include/pigo_hip.h).  The Go toolchain is not available in this image, so this is
+// the host side "above the C ABI" in the compiled-language form the reference itself has; INTEGRATION.md shows
+// the equivalent cgo shim.  Names, argument meaning and error behaviour follow core/pigo.go:
+//
+//     pigo::Pigo pg = pigo::NewPigo().Unpack(cascade_bytes);            // core/pigo.go:46,51
+//     pigo::CascadeParams cp{ {pixels, rows, cols, cols}, 20, 1000, 0.1, 1.1 };
+//     std::vector<pigo::Detection> dets = pg.RunCascade(cp, 0.0);        // core/pigo.go:212
+//     dets = pg.ClusterDetections(dets, 0.2);                            // core/pigo.go:262 (sorts `dets` in place)
+//
+// Where the Go code would panic (short cascade packet, pixel index out of range) a pigo::Panic is thrown; other
+// failures throw std::runtime_error / std::invalid_argument.  There is no CPU fallback.
+#ifndef PIGO_HPP
+#define PIGO_HPP
+
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pigo_hip.h"
+
+namespace pigo {
+
+struct Panic : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// ImageParams, core/pigo.go:29-34
+struct ImageParams {
+    const std::vector<uint8_t> *Pixels = nullptr;  // row-major gray, stride Dim; owned by the caller, only read
+    int Rows = 0, Cols = 0, Dim = 0;
+};
+
+// CascadeParams, core/pigo.go:16-22
+struct CascadeParams {
+    pigo::ImageParams ImageParams;
+    int MinSize = 0, MaxSize = 0;
+    double ShiftFactor = 0.0, ScaleFactor = 0.0;
+};
+
+// Detection, core/pigo.go:195-200
+struct Detection {
+    int Row = 0, Col = 0, Scale = 0;
+    float Q = 0.0f;
+};
+
+namespace detail {
+inline void check(pigo_status st, const char *what)
+{
+    if (st == PIGO_OK) return;
+    const std::string msg = std::string(what) + ": " + pigo_last_error();
+    if (st == PIGO_ERR_PACKET || st == PIGO_ERR_PANIC) throw Panic(msg);
+    if (st == PIGO_ERR_PARAM) throw std::invalid_argument(msg);
+    throw std::runtime_error(msg);
+}
+struct Deleter {
+    void operator()(pigo_cascade *c) const { pigo_cascade_destroy(c); }
+};
+}  // namespace detail
+
+class Pigo {
+public:
+    Pigo() = default;
+    explicit Pigo(int device) : device_(device) {}
+
+    // Unpack returns a NEW Pigo and leaves the receiver untouched (core/pigo.go:51,103-109)
+    Pigo Unpack(const std::vector<uint8_t> &packet) const
+    {
+        pigo_cascade *c = nullptr;
+        detail::check(pigo_cascade_create(packet.data(), packet.size(), device_, &c), "Unpack");
+        Pigo out(device_);
+        out.h_.reset(c, detail::Deleter());
+        return out;
+    }
+
+    // RunCascade, core/pigo.go:212-258: detections with q > 0 in scale-major / row / col order
+    std::vector<Detection> RunCascade(const CascadeParams &cp, double angle) const
+    {
+        need();
+        const ImageParams &ip = cp.ImageParams;
+        if (!ip.Pixels) throw std::invalid_argument("RunCascade: ImageParams.Pixels is null");
+        std::vector<pigo_det> buf(1024);
+        for (;;) {
+            int n = 0;
+            pigo_status st = pigo_run_cascade(h_.get(), ip.Pixels->data(), ip.Pixels->size(), ip.Rows, ip.Cols, ip.Dim, cp.MinSize,
+                                              cp.MaxSize, cp.ShiftFactor, cp.ScaleFactor, angle, buf.data(), (int)buf.size(), &n);
+            if (st == PIGO_ERR_CAPACITY && n > (int)buf.size()) {
+                buf.resize((size_t)n);
+                continue;
+            }
+            detail::check(st, "RunCascade");
+            std::vector<Detection> out((size_t)n);
+            for (int i = 0; i < n; ++i) out[(size_t)i] = Detection{buf[(size_t)i].row, buf[(size_t)i].col, buf[(size_t)i].scale, buf[(size_t)i].q};
+            return out;  // empty vector where Go returns a nil slice (pigo.go:214)
+        }
+    }
+
+    // ClusterDetections, core/pigo.go:262-308: sorts `detections` in place (like the reference), returns the clusters
+    std::vector<Detection> ClusterDetections(std::vector<Detection> &detections, double iouThreshold) const
+    {
+        need();
+        const int n = (int)detections.size();
+        std::vector<pigo_det> in((size_t)n), out((size_t)(n > 0 ? n : 1));
+        for (int i = 0; i < n; ++i) in[(size_t)i] = pigo_det{detections[(size_t)i].Row, detections[(size_t)i].Col, detections[(size_t)i].Scale, detections[(size_t)i].Q};
+        int k = 0;
+        detail::check(pigo_cluster_detections(h_.get(), in.data(), n, iouThreshold, out.data(), (int)out.size(), &k), "ClusterDetections");
+        for (int i = 0; i < n; ++i) detections[(size_t)i] = Detection{in[(size_t)i].row, in[(size_t)i].col, in[(size_t)i].scale, in[(size_t)i].q};
+        std::vector<Detection> clusters((size_t)k);
+        for (int i = 0; i < k; ++i) clusters[(size_t)i] = Detection{out[(size_t)i].row, out[(size_t)i].col, out[(size_t)i].scale, out[(size_t)i].q};
+        return clusters;
+    }
+
+    uint32_t treeDepth() const
+    {
+        need();
+        uint32_t d = 0, n = 0;
+        detail::check(pigo_cascade_info(h_.get(), &d, &n), "info");
+        return d;
+    }
+    uint32_t treeNum() const
+    {
+        need();
+        uint32_t d = 0, n = 0;
+        detail::check(pigo_cascade_info(h_.get(), &d, &n), "info");
+        return n;
+    }
+    pigo_cascade *handle() const { return h_.get(); }  // for the batch extension (pigo_plan_*)
+
+private:
+    void need() const
+    {
+        if (!h_) throw std::runtime_error("Pigo is not unpacked (call Unpack first)");
+    }
+    int device_ = 0;
+    std::shared_ptr<pigo_cascade> h_;  // immutable after Unpack, shareable between threads like the Go struct
+};
+
+// NewPigo, core/pigo.go:46
+inline Pigo NewPigo(int device = 0) { return Pigo(device); }
+
+}  // namespace pigo
+#endif  // PIGO_HPP

@@ -1,0 +1,32 @@
+// Compile-time (and, with a GPU, run-time) check of include/pigo.hpp against libpigo_hip.so.
+// Built by tests/test_abi_cpu.py::test_cpp_mirror_compiles_and_links; with no GPU it only verifies that the
+// reference-shaped API compiles, links and reports the missing device as an exception instead of aborting.
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+
+#include "pigo.hpp"
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) return 2;
+    std::ifstream f(argv[1], std::ios::binary), g(argv[2], std::ios::binary);
+    std::vector<uint8_t> packet((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    std::vector<uint8_t> gray((std::istreambuf_iterator<char>(g)), std::istreambuf_iterator<char>());
+    try {
+        pigo::Pigo pg = pigo::NewPigo().Unpack(packet);
+        pigo::CascadeParams cp{{&gray, 400, 320, 320}, 20, 1000, 0.2, 1.1};  // core/pigo_test.go:44-50
+        std::vector<pigo::Detection> dets = pg.RunCascade(cp, 0.0);
+        std::vector<pigo::Detection> cl = pg.ClusterDetections(dets, 0.1);
+        std::printf("dets=%zu clusters=%zu", dets.size(), cl.size());
+        for (const auto &c : cl) std::printf(" (%d,%d,%d,%.4f)", c.Row, c.Col, c.Scale, c.Q);
+        std::printf("\n");
+        return cl.empty() ? 1 : 0;
+    } catch (const pigo::Panic &e) {
+        std::printf("panic: %s\n", e.what());
+        return 3;
+    } catch (const std::exception &e) {
+        std::printf("error: %s\n", e.what());
+        return 4;
+    }
+}

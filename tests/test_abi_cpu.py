@@ -97,3 +97,24 @@ def test_synthetic_frames_are_deterministic():
     assert (a == b).all() and (a != c).any()
     n = synth.syn_noise(64, 64, seed=1, frame_index=0)
     assert n.dtype == np.uint8 and 100 < n.mean() < 155
+
+
+def test_cpp_mirror_compiles_and_links(tmp_path):
+    """include/pigo.hpp (the C++ mirror of the Go API) compiles against the header, links against the library and,
+    without a GPU, reports the missing device as an exception (exit 4) instead of aborting or falling back."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not available")
+    core.load_library()
+    exe = str(tmp_path / "cpp_mirror_check")
+    csrc = os.path.join(ROOT, "pigo_amd", "csrc")
+    subprocess.check_call([gxx, "-std=c++17", "-O1", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp_mirror_check.cpp"), "-o", exe, "-L" + csrc, "-lpigo_hip", "-Wl,-rpath," + csrc])
+    r = subprocess.run([exe, os.path.join(ROOT, "pigo_amd", "data", "facefinder"), os.path.join(ROOT, "pigo_amd", "data", "sample_gray_320x400.bin")],
+                       capture_output=True, text=True)
+    if core.load_library().pigo_device_count() == 0:
+        assert r.returncode == 4 and "error:" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    else:
+        assert r.returncode == 0 and "clusters=1 (206,154,261," in r.stdout, (r.returncode, r.stdout, r.stderr)

@@ -286,3 +286,21 @@ def test_4k_config5_variants_agree_and_match_oracle(pg, orc):
     wc, ties = orc.cluster_detections(want.copy(), 0.2, want_ties=True)
     got = pg.ClusterDetections(res[1].copy(), 0.2)
     assert_same_dets(got, wc, f"4K clusters (ties={ties})", Q_TOL_RAW)
+
+
+def test_cpp_mirror_runs_on_gpu(tmp_path):
+    """include/pigo.hpp: the C++ mirror of the Go API, as a real program on the GPU (reference test parameters)."""
+    import os
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "pigo_amd", "csrc")
+    exe = str(tmp_path / "cpp_mirror_check")
+    subprocess.check_call([gxx, "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp_mirror_check.cpp"),
+                           "-o", exe, "-L" + csrc, "-lpigo_hip", "-Wl,-rpath," + csrc])
+    r = subprocess.run([exe, os.path.join(root, "pigo_amd", "data", "facefinder"), os.path.join(root, "pigo_amd", "data", "sample_gray_320x400.bin")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "dets=4 clusters=1 (206,154,261," in r.stdout, (r.returncode, r.stdout, r.stderr)
