@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--gather-cap", type=int, default=64)
     ap.add_argument("--variant", type=int, default=None, help="0 = monolithic, 1 = head+queue+tail, 2 = LDS tile (default)")
     ap.add_argument("--no-cluster", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto, ~15 s)")
     return ap.parse_args()
@@ -111,8 +112,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
@@ -140,13 +143,13 @@ def main():
             lists, lcounts = dets, counts
         else:
             _, lists, lcounts, _ = plan.cluster(dets, counts, args.iou, out=cl_out)
-        if world > 1:
+        if use_dist:
             return distributed.allgather_lists(lists, lcounts, gcap, B)
         return lists
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -160,7 +163,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     plan.status()
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -181,6 +184,9 @@ def main():
         tiles = max(st[4], 1)
         print("debug_stats (cycles per tile): copy %.0f stage0 %.0f dense %.0f late %.0f | late windows/tile %.1f late trees/tile %.1f tiles %d" %
               (st[0] / tiles, st[1] / tiles, st[2] / tiles, st[3] / tiles, st[5] / tiles, st[6] / tiles, st[4]), file=sys.stderr)
+        ne = max(st[8], 1)
+        print("debug_stats tail_deep (cycles per entry, wave 0): entry %.0f patch %.0f walk %.0f leaf %.0f accumulate %.0f | passes/entry %.2f entries %d" %
+              (st[9] / ne, st[10] / ne, st[11] / ne, st[12] / ne, st[13] / ne, st[14] / ne, st[8]), file=sys.stderr)
     ndet = int(counts.sum().item())
     cev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     cluster_ms = None
@@ -217,7 +223,7 @@ def main():
                 "workload": f"{args.cols}x{args.rows} synthetic gray frames (SYN-{args.kind.upper()}, seed {args.seed}), facefinder cascade, "
                             f"MinSize={args.min_size} MaxSize={args.max_size} Shift={args.shift} Scale={args.scale} angle={args.angle}; "
                             f"{B} HBM-resident frames per GPU per step; RunCascade + per-frame ClusterDetections(iou={args.iou})"
-                            + (f" + RCCL all-gather of {gcap}-record cluster lists" if world > 1 else ""),
+                            + (f" + RCCL all-gather of {gcap}-record cluster lists" if use_dist else ""),
                 "frames_per_gpu": B, "windows_per_frame": wpf, "scales": int(info.n_scales), "variant": int(info.variant),
                 "head_trees": int(info.n_head_trees), "detections_per_batch": ndet,
                 "head_survivor_fraction": round(survivors / (B * wpf), 5) if wpf else None,
@@ -239,7 +245,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -142,6 +142,7 @@ struct pigo_plan {
     DevBuf<uint2> d_tiles2;
     DevBuf<uint32_t> d_tabp;
     bool tile_ok = false;
+    int tile_threads = 256;              // workgroup size of the LDS-pixel classes of k_scan_tile (256 or 512)
     size_t deep_lds = 0;                 // dynamic LDS of k_tail_deep
     DevBuf<QEntry> d_queue;
     DevBuf<uint32_t> d_qcount;
@@ -388,6 +389,13 @@ bool build_tile_stages(pigo_plan &p)
             begin = i + 1;
         }
     }
+    if (env_int("PIGO_MERGE_STAGES", 0) && ends.size() >= 6 && ends[0] == 0 && ends[1] == 1 && ends[2] == 2 && ends[3] == 3) {
+        // the scan is latency-bound: fuse the single-tree stages after stage 0 pairwise ([1],[2] -> [1..2]; [3],[4..] -> [3..])
+        // and walk their trees with tree-level ILP.  Some windows then evaluate a tree they would have skipped (wasted
+        // work, not a different result: every tree's threshold is still tested in order).
+        ends.erase(ends.begin() + 3);
+        ends.erase(ends.begin() + 1);
+    }
     while ((int)ends.size() > kMaxStages) {  // too many compaction points: merge neighbours that still fit
         std::vector<int> m;
         int b = 0;
@@ -432,7 +440,7 @@ void build_tile_classes(pigo_plan &p)
 {
     std::vector<TileRule> rules;
     const char *env = getenv("PIGO_TILE_RULES");
-    std::string spec = env && *env ? env : "6,32,16384;6,16,24576;6,8,36864";
+    std::string spec = env && *env ? env : "6,32,32768;6,16,40960";
     {
         size_t pos = 0;
         while (pos < spec.size()) {
@@ -440,7 +448,7 @@ void build_tile_classes(pigo_plan &p)
             if (end == std::string::npos) end = spec.size();
             TileRule r{};
             if (sscanf(spec.substr(pos, end - pos).c_str(), "%d,%d,%lld", &r.tw_log2, &r.th, &r.max_pix) == 3 && r.tw_log2 >= 5 && r.tw_log2 <= 6 &&
-                r.th >= 1 && ((1 << r.tw_log2) * r.th) % kThreads == 0 && (1 << r.tw_log2) * r.th <= 4096)
+                r.th >= 1 && ((1 << r.tw_log2) * r.th) % 512 == 0 && (1 << r.tw_log2) * r.th <= 4096)
                 rules.push_back(r);
             pos = end + 1;
         }
@@ -479,7 +487,7 @@ void build_tile_classes(pigo_plan &p)
         }
         const size_t nwin = (size_t)(1 << pk.tw_log2) * pk.th;
         const size_t qbytes = 6 * (nwin + nwin / (p.rot ? 1 : 2));
-        pk.dyn += (size_t)p.args.tab_trees * 64 * (pk.lds ? 4 : 8) + qbytes + (qbytes >= (size_t)64 * (kWaves * kLateTrees + 1) * 4 ? 0 : (size_t)64 * (kWaves * kLateTrees + 1) * 4);
+        pk.dyn += (size_t)p.args.tab_trees * 64 * (pk.lds ? 4 : 8) + qbytes + (qbytes >= (size_t)64 * (kLateWaves * kLateTrees + 1) * 4 ? 0 : (size_t)64 * (kLateWaves * kLateTrees + 1) * 4);
         pk.bucket = (int)(sizeof(buckets) / sizeof(buckets[0])) - 1;
         for (int b = 0; b < (int)(sizeof(buckets) / sizeof(buckets[0])); ++b)
             if (pk.dyn <= buckets[b]) {
@@ -594,10 +602,12 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
         const int max_dyn = (160 << 10) - 1024;
-        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, true, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        p->tile_threads = env_int("PIGO_TILE_THREADS", 256) == 512 ? 512 : 256;
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
@@ -612,12 +622,12 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.tiles2 = p->d_tiles2.p;
     a.tabp = p->d_tabp.p;
     a.codes = c->d_codes.p;
-    a.late_waves = std::max(1, std::min(kWaves, env_int("PIGO_LATE_WAVES", kWaves)));
+    a.late_waves = std::max(1, std::min(kLateWaves, env_int("PIGO_LATE_WAVES", kLateWaves)));
     a.qb_div = p->rot ? 1 : 2;
     a.stats = nullptr;
     if (env_int("PIGO_DEBUG_STATS", 0)) {
-        HIP_TRY(p->d_stats.alloc(65536 * 8 + 16 * 256));
-        HIP_TRY(hipMemset(p->d_stats.p, 0, (65536 * 8 + 16 * 256) * 8));
+        HIP_TRY(p->d_stats.alloc(65536 * 8 + 16 * 256 + 256 * 8));
+        HIP_TRY(hipMemset(p->d_stats.p, 0, (65536 * 8 + 16 * 256 + 256 * 8) * 8));
         a.stats = p->d_stats.p;
     }
     a.qcos = kQCos[p->angle_idx];
@@ -661,13 +671,18 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             ca.nwin = cls.nwin;
             const uint32_t grid = (uint32_t)a.nframes * cls.ntiles;
             mark(cls.lds ? "scan_tile_lds" : "scan_tile_glb");
+            const bool wide = p.tile_threads == 512;
             if constexpr (!ROT) {
-                if (cls.lds)
-                    k_scan_tile<false, false, true><<<grid, kThreads, cls.dyn_lds, s>>>(ca);
-                else
-                    k_scan_tile<false, false, false><<<grid, kThreads, cls.dyn_lds, s>>>(ca);
+                if (cls.lds) {
+                    if (wide)
+                        k_scan_tile<false, false, true, 512><<<grid, 512, cls.dyn_lds, s>>>(ca);
+                    else
+                        k_scan_tile<false, false, true, 256><<<grid, 256, cls.dyn_lds, s>>>(ca);
+                } else {
+                    k_scan_tile<false, false, false, 256><<<grid, 256, cls.dyn_lds, s>>>(ca);
+                }
             } else {
-                k_scan_tile<true, GUARD, false><<<grid, kThreads, cls.dyn_lds, s>>>(ca);
+                k_scan_tile<true, GUARD, false, 256><<<grid, 256, cls.dyn_lds, s>>>(ca);
             }
         }
         if (a.deep_lo < a.ntrees) {
@@ -870,6 +885,13 @@ extern "C" pigo_status pigo_plan_debug_stats(pigo_plan *p, uint64_t *out, int n)
     HIP_TRY(hipMemset(p->d_stats.p, 0, h.size() * 8));
     for (size_t b = 0; b < 65536; ++b)
         for (int k = 0; k < 8 && k < n; ++k) out[k] += h[b * 8 + k];
+    if (n >= 16) {  // [8..15]: k_tail_deep phases (wave 0 of every workgroup)
+        std::vector<unsigned long long> t(256 * 8);
+        HIP_TRY(hipMemcpy(t.data(), p->d_stats.p + 65536 * 8 + 4096, t.size() * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(p->d_stats.p + 65536 * 8 + 4096, 0, t.size() * 8));
+        for (size_t b = 0; b < 256; ++b)
+            for (int k = 0; k < 8; ++k) out[8 + k] += t[b * 8 + k];
+    }
     return PIGO_OK;
 }
 

@@ -1,0 +1,15 @@
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -6 gpurun_out/pytest_gpu.log | cut -c1-200
+run() { name=$1; shift; timeout 300 python bench.py --frames 64 --steps 5 --warmup 2 --no-cpu-baseline "$@" > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err; echo "bench $name rc=$?"; grep debug_stats gpurun_out/bench_$name.err; python - <<PY
+import json
+try:
+    d=json.load(open("gpurun_out/bench_$name.json")); print("$name", d["value"], "Mwin/s", d["frames_per_s"], "fps", d["kernel_ms"], "surv", d["config"]["head_survivor_fraction"])
+except Exception as e: print("$name FAILED", e); print(open("gpurun_out/bench_$name.err").read()[-1500:])
+PY
+}
+run v2_default
+run v2_noise --kind noise
+PIGO_DEBUG_STATS=1 PIGO_TILE_RULES="6,32,16384" run dbg_small32
+PIGO_TILE_RULES="6,32,16384;6,32,32768;6,16,40960" run v2_big
+PIGO_TILE_RULES="6,32,16384;6,16,24576;6,8,36864;6,8,57344" run v2_mid8
+run v2_rot --angle 0.8

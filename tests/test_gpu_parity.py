@@ -211,7 +211,7 @@ def test_batch_api_matches_single_frame_and_is_order_stable(pg, orc):
                 assert_same_dets(srt[f], w, f"batch sorted frame {f}", Q_TOL_RAW)
 
 
-@pytest.mark.parametrize("rules", ["5,8,20480", "6,32,40000;6,4,60000", "6,4,4096"])
+@pytest.mark.parametrize("rules", ["5,16,20480", "6,32,40000;6,8,60000", "6,8,4096"])
 def test_tile_geometry_rules(orc, rules, monkeypatch):
     """Variant 2 with unusual tile geometries (32-wide tiles, 2048-window tiles, almost everything on the
     global-memory class): the result may not depend on how the index space is tiled."""
