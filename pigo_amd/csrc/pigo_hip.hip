@@ -788,7 +788,7 @@ extern "C" pigo_status pigo_plan_info(const pigo_plan *p, pigo_plan_info_t *info
     info->n_scales = (int32_t)p->scales.size();
     info->n_ladder = p->n_ladder;
     info->tiles_per_frame = (int32_t)p->tiles.size();
-    info->n_head_trees = p->args.nh;
+    info->n_head_trees = p->variant == 2 ? p->args.nh_lds : p->args.nh;
     info->variant = p->variant;
     info->max_frames = p->max_frames;
     info->det_cap = p->det_cap;

@@ -1,0 +1,16 @@
+# Round-1 measurement: parity suite, smoke, the default bench line, the RCCL path at world size 1, rocprofv3 trace + PMC passes
+mkdir -p gpurun_out/prof_r1f && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+nproc > gpurun_out/prof_r1f/host.txt; (rocminfo | grep -m3 "Marketing Name" ) >> gpurun_out/prof_r1f/host.txt 2>&1
+timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_gpu.log | cut -c1-200
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
+timeout 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench rc=$?"; cat gpurun_out/bench_default.json
+timeout 300 python bench.py --force-dist --frames 32 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_dist1.json 2> gpurun_out/bench_dist1.err; echo "dist1 rc=$?"; cut -c1-300 gpurun_out/bench_dist1.json; tail -3 gpurun_out/bench_dist1.err
+timeout 300 python bench.py --kind noise --no-cpu-baseline > gpurun_out/bench_noise.json 2> gpurun_out/bench_noise.err; echo "noise rc=$?"; cut -c1-400 gpurun_out/bench_noise.json
+timeout 300 python bench.py --angle 0.8 --no-cpu-baseline > gpurun_out/bench_rot.json 2> gpurun_out/bench_rot.err; echo "rot rc=$?"; cut -c1-400 gpurun_out/bench_rot.json
+B="python bench.py --frames 64 --steps 5 --warmup 2 --no-cpu-baseline"
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r1f/trace -o t -- $B > gpurun_out/prof_r1f/trace.log 2>&1; echo "trace rc=$?"
+timeout 600 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_r1f/pmc_fetch -o p -- $B > gpurun_out/prof_r1f/pmc_fetch.log 2>&1; echo "pmc_fetch rc=$?"
+timeout 600 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof_r1f/pmc_write -o p -- $B > gpurun_out/prof_r1f/pmc_write.log 2>&1; echo "pmc_write rc=$?"
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d gpurun_out/prof_r1f/pmc_sq -o p -- $B > gpurun_out/prof_r1f/pmc_sq.log 2>&1; echo "pmc_sq rc=$?"
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d gpurun_out/prof_r1f/pmc_sq2 -o p -- $B > gpurun_out/prof_r1f/pmc_sq2.log 2>&1; echo "pmc_sq2 rc=$?"
+du -sh gpurun_out/prof_r1f
