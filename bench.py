@@ -185,8 +185,7 @@ def main():
         print("debug_stats (cycles per tile): copy %.0f stage0 %.0f dense %.0f late %.0f | late windows/tile %.1f late trees/tile %.1f tiles %d" %
               (st[0] / tiles, st[1] / tiles, st[2] / tiles, st[3] / tiles, st[5] / tiles, st[6] / tiles, st[4]), file=sys.stderr)
         ne = max(st[8], 1)
-        print("debug_stats tail_deep (cycles per entry, wave 0): entry %.0f patch %.0f walk %.0f leaf %.0f accumulate %.0f | passes/entry %.2f entries %d" %
-              (st[9] / ne, st[10] / ne, st[11] / ne, st[12] / ne, st[13] / ne, st[14] / ne, st[8]), file=sys.stderr)
+        print("debug_stats tail_deep (wave 0): %.0f cycles per entry | passes/entry %.2f entries %d" % (st[9] / ne, st[14] / ne, st[8]), file=sys.stderr)
     ndet = int(counts.sum().item())
     cev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     cluster_ms = None
