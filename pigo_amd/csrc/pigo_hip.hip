@@ -142,6 +142,7 @@ struct pigo_plan {
     DevBuf<uint2> d_tiles2;
     DevBuf<uint32_t> d_tabp;
     bool tile_ok = false;
+    int tab_lds = 0, tab_glb = 0;        // LDS table capacity (trees) of the LDS-pixel / global-pixel classes
     int tile_threads = 256;              // workgroup size of the LDS-pixel classes of k_scan_tile (256 or 512)
     size_t deep_lds = 0;                 // dynamic LDS of k_tail_deep
     DevBuf<QEntry> d_queue;
@@ -373,9 +374,13 @@ bool build_tile_stages(pigo_plan &p)
     for (int i = 0; i < nt; ++i) lo = std::min(lo, c.thr[i]);
     ScanArgs &a = p.args;
     a.nh_lds = std::min(nt, std::max(1, env_int("PIGO_NH_LDS", 28)));
-    a.nh_glb = std::min(nt, std::max(1, env_int("PIGO_NH_GLB", 18)));
+    a.nh_glb = std::min(nt, std::max(1, p.rot ? env_int("PIGO_NH_ROT", 18) : env_int("PIGO_NH_GLB", 28)));
     a.deep_lo = std::min(a.nh_lds, a.nh_glb);
-    a.tab_trees = std::min(kTabTrees, std::max(std::max(a.nh_lds, a.nh_glb), 8));
+    // LDS table capacity per class: enough for the trees the class walks before handing off; the dense stages'
+    // table windows are planned for the smaller of the two so that they fit either
+    p.tab_lds = std::min(kTabTrees, std::max(a.nh_lds, 8));
+    p.tab_glb = std::min(kTabTrees, std::max(a.nh_glb, 8));
+    a.tab_trees = p.rot ? p.tab_glb : std::min(p.tab_lds, p.tab_glb);
     const int cap = a.tab_trees;
     std::vector<int> ends;
     int begin = 0;
@@ -487,7 +492,7 @@ void build_tile_classes(pigo_plan &p)
         }
         const size_t nwin = (size_t)(1 << pk.tw_log2) * pk.th;
         const size_t qbytes = 6 * (nwin + nwin / (p.rot ? 1 : 2));
-        pk.dyn += (size_t)p.args.tab_trees * 64 * (pk.lds ? 4 : 8) + qbytes + (qbytes >= (size_t)64 * (kLateWaves * kLateTrees + 1) * 4 ? 0 : (size_t)64 * (kLateWaves * kLateTrees + 1) * 4);
+        pk.dyn += (size_t)(pk.lds ? p.tab_lds : p.tab_glb) * 64 * (pk.lds ? 4 : 8) + qbytes + (qbytes >= (size_t)64 * (kLateWaves * kLateTrees + 1) * 4 ? 0 : (size_t)64 * (kLateWaves * kLateTrees + 1) * 4);
         pk.bucket = (int)(sizeof(buckets) / sizeof(buckets[0])) - 1;
         for (int b = 0; b < (int)(sizeof(buckets) / sizeof(buckets[0])); ++b)
             if (pk.dyn <= buckets[b]) {
@@ -669,6 +674,7 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             ca.tw_log2 = cls.tw_log2;
             ca.th = cls.th;
             ca.nwin = cls.nwin;
+            ca.tab_trees = cls.lds ? p.tab_lds : p.tab_glb;
             const uint32_t grid = (uint32_t)a.nframes * cls.ntiles;
             mark(cls.lds ? "scan_tile_lds" : "scan_tile_glb");
             const bool wide = p.tile_threads == 512;
