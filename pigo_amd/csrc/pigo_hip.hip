@@ -144,7 +144,10 @@ struct pigo_plan {
     bool tile_ok = false;
     int tab_lds = 0, tab_glb = 0;        // LDS table capacity (trees) of the LDS-pixel / global-pixel classes
     int tile_threads = 256;              // workgroup size of the LDS-pixel classes of k_scan_tile (256 or 512)
-    size_t deep_lds = 0;                 // dynamic LDS of k_tail_deep
+    size_t deep_lds = 0, deep_lds2 = 0;  // dynamic LDS of the two k_tail_deep launches
+    int deep_mid = 0;                    // first launch walks [deep_lo, deep_mid), second [deep_mid, ntrees)
+    DevBuf<QEntry> d_queue2;
+    long long qcap2 = 0;
     DevBuf<QEntry> d_queue;
     DevBuf<uint32_t> d_qcount;
     DevBuf<RawDet> d_raw;
@@ -165,7 +168,7 @@ struct pigo_plan {
     }
     size_t workspace_bytes() const
     {
-        return d_scales.bytes() + d_tiles.bytes() + d_tiles2.bytes() + d_tabp.bytes() + d_tab.bytes() + d_queue.bytes() + d_qcount.bytes() + d_raw.bytes() + d_flags.bytes() +
+        return d_scales.bytes() + d_tiles.bytes() + d_tiles2.bytes() + d_tabp.bytes() + d_tab.bytes() + d_queue.bytes() + d_queue2.bytes() + d_qcount.bytes() + d_raw.bytes() + d_flags.bytes() +
                d_mq.bytes();
     }
 };
@@ -417,8 +420,12 @@ bool build_tile_stages(pigo_plan &p)
         ends.swap(m);
     }
     a.n_stages = (int)ends.size();
-    p.deep_lds = (size_t)(nt - a.deep_lo) * kCodeStride * 4 + (size_t)kDeepWaves * kPatchBytes;
-    if (p.deep_lds > (size_t)(160 << 10) - 1024) return false;  // the deep trees' codes must fit one CU's LDS
+    // two launches of k_tail_deep: the first two passes (128 trees) with a small code table -> two workgroups per CU;
+    // the few windows that survive them continue in a second launch holding the remaining codes
+    p.deep_mid = std::min(nt, a.deep_lo + std::max(64, env_int("PIGO_DEEP_SPLIT", 128)));
+    p.deep_lds = (size_t)(p.deep_mid - a.deep_lo) * kCodeStride * 4 + (size_t)kDeepWaves * kPatchBytes;
+    p.deep_lds2 = (size_t)(nt - p.deep_mid) * kCodeStride * 4 + (size_t)kDeepWaves * kPatchBytes;
+    if (p.deep_lds > (size_t)(160 << 10) - 1024 || p.deep_lds2 > (size_t)(160 << 10) - 1024) return false;  // codes must fit one CU's LDS
     int hi = 0;  // trees [.., hi) are resident
     for (int st = 0; st < a.n_stages; ++st) {
         const int t0 = st == 0 ? 0 : ends[st - 1] + 1;
@@ -445,7 +452,7 @@ void build_tile_classes(pigo_plan &p)
 {
     std::vector<TileRule> rules;
     const char *env = getenv("PIGO_TILE_RULES");
-    std::string spec = env && *env ? env : "6,32,32768;6,16,40960";
+    std::string spec = env && *env ? env : "6,32,16384;6,16,40960";
     {
         size_t pos = 0;
         while (pos < spec.size()) {
@@ -540,7 +547,9 @@ pigo_status plan_alloc_batch(pigo_plan &p, int max_frames, int det_cap)
     qcap = (qcap + kTailChunk - 1) / kTailChunk * kTailChunk;
     p.qcap = qcap;
     HIP_TRY(p.d_queue.alloc((size_t)qcap * max_frames));
-    HIP_TRY(p.d_qcount.alloc(max_frames));
+    HIP_TRY(p.d_qcount.alloc(std::max(max_frames, 2)));
+    p.qcap2 = std::max<long long>(4096, (qcap * (long long)max_frames) / 8);
+    HIP_TRY(p.d_queue2.alloc((size_t)p.qcap2));
     HIP_TRY(p.d_raw.alloc((size_t)det_cap * max_frames));
     HIP_TRY(p.d_mq.alloc((size_t)det_cap * max_frames));
     return PIGO_OK;
@@ -695,7 +704,24 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             mark("tail_deep");
             ScanArgs ta = a;
             ta.qcap = (uint32_t)std::min<long long>(p.qcap * (long long)p.max_frames, 0xffffffffLL);
-            k_tail_deep<ROT, GUARD><<<256, kDeepThreads, p.deep_lds, s>>>(ta);
+            ta.deep_hi = p.deep_mid;
+            ta.queue2 = p.d_queue2.p;
+            ta.qcount2 = p.d_qcount.p + 1;
+            ta.qcap2 = (uint32_t)p.qcap2;
+            k_tail_deep<ROT, GUARD><<<(p.deep_lds * 2 <= (size_t)(158 << 10)) ? 512 : 256, kDeepThreads, p.deep_lds, s>>>(ta);
+            if (p.deep_mid < a.ntrees) {
+                mark("tail_deep2");
+                ScanArgs tb = a;
+                tb.queue = p.d_queue2.p;
+                tb.qcount = p.d_qcount.p + 1;
+                tb.qcap = (uint32_t)p.qcap2;
+                tb.deep_lo = p.deep_mid;
+                tb.deep_hi = a.ntrees;
+                tb.queue2 = nullptr;
+                tb.qcount2 = nullptr;
+                tb.qcap2 = 0;
+                k_tail_deep<ROT, GUARD><<<256, kDeepThreads, p.deep_lds2, s>>>(tb);
+            }
         }
     } else if (variant == 1) {
         mark("scan_head");
@@ -731,7 +757,7 @@ pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame
     a.nframes = nframes;
     a.counts = d_counts;
     a.tail_wgs = std::max(8, std::min(256, 2048 / nframes));
-    if (variant >= 1) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)nframes * 4, s));
+    if (variant >= 1) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)std::max(nframes, 2) * 4, s));
 
     size_t ev = 0;
     auto mark = [&](const char *name) {
@@ -909,6 +935,10 @@ extern "C" pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n)
     *n = 0;
     if (p->last_nframes == 0) return PIGO_OK;
     HIP_TRY(hipMemcpy(h.data(), p->d_qcount.p, (size_t)p->last_nframes * 4, hipMemcpyDeviceToHost));
+    if (p->variant == 2) {
+        *n = h[0];  // one queue for the whole batch ([1] counts the second-level tail)
+        return PIGO_OK;
+    }
     for (uint32_t v : h) *n += v;
     return PIGO_OK;
 }
