@@ -843,6 +843,7 @@ extern "C" pigo_status pigo_plan_run(pigo_plan *p, const uint8_t *d_frames, size
                                      int32_t *d_counts, void *stream)
 {
     if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
+    std::lock_guard<std::mutex> lock(p->mu);  // a plan owns one workspace: launches on it are serialised
     return plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, (hipStream_t)stream, p->variant);
 }
 
@@ -862,6 +863,7 @@ extern "C" pigo_status pigo_plan_run_sync(pigo_plan *p, const uint8_t *d_frames,
                                           int32_t *d_counts, void *stream)
 {
     if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
+    std::lock_guard<std::mutex> lock(p->mu);
     hipStream_t s = (hipStream_t)stream;
     pigo_status st = plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, s, p->variant);
     if (st != PIGO_OK) return st;
