@@ -547,7 +547,7 @@ pigo_status plan_alloc_batch(pigo_plan &p, int max_frames, int det_cap)
     qcap = (qcap + kTailChunk - 1) / kTailChunk * kTailChunk;
     p.qcap = qcap;
     HIP_TRY(p.d_queue.alloc((size_t)qcap * max_frames));
-    HIP_TRY(p.d_qcount.alloc(std::max(max_frames, 2)));
+    HIP_TRY(p.d_qcount.alloc(std::max(max_frames, 16)));
     p.qcap2 = std::max<long long>(4096, (qcap * (long long)max_frames) / 8);
     HIP_TRY(p.d_queue2.alloc((size_t)p.qcap2));
     HIP_TRY(p.d_raw.alloc((size_t)det_cap * max_frames));
@@ -677,7 +677,7 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
         for (const pigo_plan::TileClass &cls : p.classes) {
             if (cls.ntiles == 0) continue;
             ScanArgs ca = a;
-            ca.qcap = (uint32_t)std::min<long long>(p.qcap * (long long)p.max_frames, 0xffffffffLL);
+            ca.qcap = (uint32_t)std::min<long long>(p.qcap * (long long)p.max_frames / 8, 0xffffffffLL);  // per XCD queue
             ca.cls_tile0 = cls.tile0;
             ca.cls_ntiles = cls.ntiles;
             ca.tw_log2 = cls.tw_log2;
@@ -703,17 +703,19 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
         if (a.deep_lo < a.ntrees) {
             mark("tail_deep");
             ScanArgs ta = a;
-            ta.qcap = (uint32_t)std::min<long long>(p.qcap * (long long)p.max_frames, 0xffffffffLL);
+            ta.qcap = (uint32_t)std::min<long long>(p.qcap * (long long)p.max_frames / 8, 0xffffffffLL);
+            ta.nqueues = 8;
             ta.deep_hi = p.deep_mid;
             ta.queue2 = p.d_queue2.p;
-            ta.qcount2 = p.d_qcount.p + 1;
+            ta.qcount2 = p.d_qcount.p + 8;
             ta.qcap2 = (uint32_t)p.qcap2;
             k_tail_deep<ROT, GUARD><<<(p.deep_lds * 2 <= (size_t)(158 << 10)) ? 512 : 256, kDeepThreads, p.deep_lds, s>>>(ta);
             if (p.deep_mid < a.ntrees) {
                 mark("tail_deep2");
                 ScanArgs tb = a;
                 tb.queue = p.d_queue2.p;
-                tb.qcount = p.d_qcount.p + 1;
+                tb.nqueues = 1;
+                tb.qcount = p.d_qcount.p + 8;
                 tb.qcap = (uint32_t)p.qcap2;
                 tb.deep_lo = p.deep_mid;
                 tb.deep_hi = a.ntrees;
@@ -757,7 +759,7 @@ pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame
     a.nframes = nframes;
     a.counts = d_counts;
     a.tail_wgs = std::max(8, std::min(256, 2048 / nframes));
-    if (variant >= 1) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)std::max(nframes, 2) * 4, s));
+    if (variant >= 1) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)std::max(nframes, 16) * 4, s));
 
     size_t ev = 0;
     auto mark = [&](const char *name) {
@@ -938,7 +940,10 @@ extern "C" pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n)
     if (p->last_nframes == 0) return PIGO_OK;
     HIP_TRY(hipMemcpy(h.data(), p->d_qcount.p, (size_t)p->last_nframes * 4, hipMemcpyDeviceToHost));
     if (p->variant == 2) {
-        *n = h[0];  // one queue for the whole batch ([1] counts the second-level tail)
+        uint32_t h8[8] = {0};
+        HIP_TRY(hipMemcpy(h8, p->d_qcount.p, sizeof h8, hipMemcpyDeviceToHost));
+        *n = 0;
+        for (uint32_t v : h8) *n += v;  // eight per-XCD queues ([8] counts the second-level tail)
         return PIGO_OK;
     }
     for (uint32_t v : h) *n += v;
