@@ -144,6 +144,7 @@ struct pigo_plan {
     bool tile_ok = false;
     int tab_lds = 0, tab_glb = 0;        // LDS table capacity (trees) of the LDS-pixel / global-pixel classes
     int tile_threads = 256;              // workgroup size of the LDS-pixel classes of k_scan_tile (256 or 512)
+    bool tab_global = false;             // LDS-pixel classes read their offset tables from global memory (L1) instead of LDS
     size_t deep_lds = 0, deep_lds2 = 0;  // dynamic LDS of the two k_tail_deep launches
     int deep_mid = 0;                    // first launch walks [deep_lo, deep_mid), second [deep_mid, ntrees)
     DevBuf<QEntry> d_queue2;
@@ -499,7 +500,7 @@ void build_tile_classes(pigo_plan &p)
         }
         const size_t nwin = (size_t)(1 << pk.tw_log2) * pk.th;
         const size_t qbytes = 6 * (nwin + nwin / (p.rot ? 1 : 2));
-        pk.dyn += (size_t)(pk.lds ? p.tab_lds : p.tab_glb) * 64 * (pk.lds ? 4 : 8) + qbytes + (qbytes >= (size_t)64 * (kLateWaves * kLateTrees + 1) * 4 ? 0 : (size_t)64 * (kLateWaves * kLateTrees + 1) * 4);
+        pk.dyn += (size_t)(pk.lds ? (p.tab_global ? 0 : p.tab_lds) : p.tab_glb) * 64 * (pk.lds ? 4 : 8) + qbytes + (qbytes >= (size_t)64 * (kLateWaves * kLateTrees + 1) * 4 ? 0 : (size_t)64 * (kLateWaves * kLateTrees + 1) * 4);
         pk.bucket = (int)(sizeof(buckets) / sizeof(buckets[0])) - 1;
         for (int b = 0; b < (int)(sizeof(buckets) / sizeof(buckets[0])); ++b)
             if (pk.dyn <= buckets[b]) {
@@ -585,6 +586,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     pigo_status st = build_ladder(*p);
     if (st != PIGO_OK) return st;
 
+    p->tab_global = env_int("PIGO_TAB_GLOBAL", 0) != 0;
     p->tile_ok = build_tile_stages(*p);
     build_tile_classes(*p);  // also fills ScaleDesc::pitch / up
 
@@ -616,11 +618,12 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
         const int max_dyn = (160 << 10) - 1024;
-        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, true, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, false, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, true, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         p->tile_threads = env_int("PIGO_TILE_THREADS", 256) == 512 ? 512 : 256;
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
@@ -689,15 +692,19 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             const bool wide = p.tile_threads == 512;
             if constexpr (!ROT) {
                 if (cls.lds) {
-                    if (wide)
-                        k_scan_tile<false, false, true, 512><<<grid, 512, cls.dyn_lds, s>>>(ca);
-                    else
-                        k_scan_tile<false, false, true, 256><<<grid, 256, cls.dyn_lds, s>>>(ca);
+                    if (p.tab_global) {
+                        ca.tab_trees = 0;  // no table region in LDS
+                        k_scan_tile<false, false, true, 256, false><<<grid, 256, cls.dyn_lds, s>>>(ca);
+                    } else if (wide) {
+                        k_scan_tile<false, false, true, 512, true><<<grid, 512, cls.dyn_lds, s>>>(ca);
+                    } else {
+                        k_scan_tile<false, false, true, 256, true><<<grid, 256, cls.dyn_lds, s>>>(ca);
+                    }
                 } else {
-                    k_scan_tile<false, false, false, 256><<<grid, 256, cls.dyn_lds, s>>>(ca);
+                    k_scan_tile<false, false, false, 256, true><<<grid, 256, cls.dyn_lds, s>>>(ca);
                 }
             } else {
-                k_scan_tile<true, GUARD, false, 256><<<grid, 256, cls.dyn_lds, s>>>(ca);
+                k_scan_tile<true, GUARD, false, 256, true><<<grid, 256, cls.dyn_lds, s>>>(ca);
             }
         }
         if (a.deep_lo < a.ntrees) {
