@@ -163,9 +163,22 @@ struct pigo_plan {
     int n_timed = 0;
     int last_nframes = 0;
     std::mutex mu;
+    // the global-gather tile classes (vector-memory bound) run on a side stream next to the LDS-tile classes (LDS bound)
+    hipStream_t side = nullptr;
+    hipStream_t side2[3] = {nullptr, nullptr, nullptr};  // PIGO_SIDE_STREAM=2: every tile class on its own stream
+    hipEvent_t ev_join2[3] = {nullptr, nullptr, nullptr};
+    int side_mode = 1;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~pigo_plan()
     {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
+        for (int i = 0; i < 3; ++i) {
+            if (ev_join2[i]) (void)hipEventDestroy(ev_join2[i]);
+            if (side2[i]) (void)hipStreamDestroy(side2[i]);
+        }
     }
     size_t workspace_bytes() const
     {
@@ -625,6 +638,17 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, false, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, true, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         p->tile_threads = env_int("PIGO_TILE_THREADS", 256) == 512 ? 512 : 256;
+        p->side_mode = env_int("PIGO_SIDE_STREAM", 1);
+        if (p->side_mode == 2)
+            for (int i = 0; i < 3; ++i) {
+                HIP_TRY(hipStreamCreateWithFlags(&p->side2[i], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&p->ev_join2[i], hipEventDisableTiming));
+            }
+        if (p->side_mode) {
+            HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+        }
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
@@ -677,8 +701,26 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
 {
     const uint32_t nb = (uint32_t)a.nframes * (uint32_t)a.ntiles;
     if (variant == 2) {
+        // fork: classes that gather from global memory go to the side stream when the plan also has LDS-tile classes
+        bool has_lds = false, has_glb = false;
+        for (const pigo_plan::TileClass &cls : p.classes)
+            if (cls.ntiles) (cls.lds ? has_lds : has_glb) = true;
+        const bool fork = p.side && has_lds && has_glb && !p.profiling;
+        const bool fork_all = fork && p.side_mode == 2;
+        if (fork) {
+            (void)hipEventRecord(p.ev_fork, s);
+            (void)hipStreamWaitEvent(p.side, p.ev_fork, 0);
+            if (fork_all)
+                for (int i = 0; i < 3; ++i) (void)hipStreamWaitEvent(p.side2[i], p.ev_fork, 0);
+        }
+        int lds_idx = 0;
         for (const pigo_plan::TileClass &cls : p.classes) {
             if (cls.ntiles == 0) continue;
+            hipStream_t cs = (fork && !cls.lds) ? p.side : s;
+            if (fork_all && cls.lds) {
+                if (lds_idx > 0 && lds_idx <= 3) cs = p.side2[lds_idx - 1];
+                ++lds_idx;
+            }
             ScanArgs ca = a;
             ca.qcap = (uint32_t)std::min<long long>(p.qcap * (long long)p.max_frames / 8, 0xffffffffLL);  // per XCD queue
             ca.cls_tile0 = cls.tile0;
@@ -694,18 +736,27 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
                 if (cls.lds) {
                     if (p.tab_global) {
                         ca.tab_trees = 0;  // no table region in LDS
-                        k_scan_tile<false, false, true, 256, false><<<grid, 256, cls.dyn_lds, s>>>(ca);
+                        k_scan_tile<false, false, true, 256, false><<<grid, 256, cls.dyn_lds, cs>>>(ca);
                     } else if (wide) {
-                        k_scan_tile<false, false, true, 512, true><<<grid, 512, cls.dyn_lds, s>>>(ca);
+                        k_scan_tile<false, false, true, 512, true><<<grid, 512, cls.dyn_lds, cs>>>(ca);
                     } else {
-                        k_scan_tile<false, false, true, 256, true><<<grid, 256, cls.dyn_lds, s>>>(ca);
+                        k_scan_tile<false, false, true, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
                     }
                 } else {
-                    k_scan_tile<false, false, false, 256, true><<<grid, 256, cls.dyn_lds, s>>>(ca);
+                    k_scan_tile<false, false, false, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
                 }
             } else {
-                k_scan_tile<true, GUARD, false, 256, true><<<grid, 256, cls.dyn_lds, s>>>(ca);
+                k_scan_tile<true, GUARD, false, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
             }
+        }
+        if (fork) {
+            (void)hipEventRecord(p.ev_join, p.side);
+            (void)hipStreamWaitEvent(s, p.ev_join, 0);
+            if (fork_all)
+                for (int i = 0; i < 3; ++i) {
+                    (void)hipEventRecord(p.ev_join2[i], p.side2[i]);
+                    (void)hipStreamWaitEvent(s, p.ev_join2[i], 0);
+                }
         }
         if (a.deep_lo < a.ntrees) {
             mark("tail_deep");
