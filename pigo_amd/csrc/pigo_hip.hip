@@ -133,6 +133,7 @@ struct pigo_plan {
     // variant 2 (k_scan_tile): tile classes = (geometry, LDS footprint bucket), one launch per class
     struct TileClass {
         int tw_log2, th, nwin;
+        int qb_div;                      // LDS queue B holds nwin / qb_div entries
         bool lds;
         uint32_t tile0, ntiles;
         size_t dyn_lds;
@@ -488,6 +489,7 @@ void build_tile_classes(pigo_plan &p)
         bool lds;
         size_t dyn;
         int bucket;
+        int qb_div;
     };
     std::vector<Pick> picks(p.scales.size());
     for (size_t k = 0; k < p.scales.size(); ++k) {
@@ -495,7 +497,10 @@ void build_tile_classes(pigo_plan &p)
         const int up = (sd.s + 1) / 2, down = (127 * sd.s) >> 8;
         sd.up = up;
         sd.pitch = 0;
-        Pick pk{g_tw_log2, g_th, false, 0, 0};
+        // LDS queues: 1.5 tiles' worth of entries shared by the two ping-pong regions (2 for the rotated scan); an overflow
+        // (stage 0 and stage 1 survivors together exceeding that) is caught on the device
+        const int qb_div = (p.rot || env_int("PIGO_QB_DIV", 2) == 1) ? 1 : 2;
+        Pick pk{g_tw_log2, g_th, false, 0, 0, qb_div};
         if (lds_allowed) {
             for (const TileRule &r : rules) {
                 const int tw = 1 << r.tw_log2;
@@ -507,12 +512,12 @@ void build_tile_classes(pigo_plan &p)
                 if (pix > r.max_pix) continue;
                 if ((long long)up * pitch + up > 32767) continue;  // offsets must fit the packed int16 table
                 sd.pitch = (int32_t)pitch;
-                pk = Pick{r.tw_log2, r.th, true, (size_t)((pix + 15) / 16 * 16), 0};
+                pk = Pick{r.tw_log2, r.th, true, (size_t)((pix + 15) / 16 * 16), 0, qb_div};
                 break;
             }
         }
         const size_t nwin = (size_t)(1 << pk.tw_log2) * pk.th;
-        const size_t qbytes = 6 * (nwin + nwin / (p.rot ? 1 : 2));
+        const size_t qbytes = 6 * (nwin + nwin / pk.qb_div);
         pk.dyn += (size_t)(pk.lds ? (p.tab_global ? 0 : p.tab_lds) : p.tab_glb) * 64 * (pk.lds ? 4 : 8) + qbytes + (qbytes >= (size_t)64 * (kLateWaves * kLateTrees + 1) * 4 ? 0 : (size_t)64 * (kLateWaves * kLateTrees + 1) * 4);
         pk.bucket = (int)(sizeof(buckets) / sizeof(buckets[0])) - 1;
         for (int b = 0; b < (int)(sizeof(buckets) / sizeof(buckets[0])); ++b)
@@ -527,10 +532,10 @@ void build_tile_classes(pigo_plan &p)
     std::vector<char> done(p.scales.size(), 0);
     for (size_t k = 0; k < p.scales.size(); ++k) {
         if (done[k]) continue;
-        pigo_plan::TileClass cls{picks[k].tw_log2, picks[k].th, (1 << picks[k].tw_log2) * picks[k].th, picks[k].lds, (uint32_t)p.tiles2.size(), 0, 0};
+        pigo_plan::TileClass cls{picks[k].tw_log2, picks[k].th, (1 << picks[k].tw_log2) * picks[k].th, picks[k].qb_div, picks[k].lds, (uint32_t)p.tiles2.size(), 0, 0};
         for (size_t j = k; j < p.scales.size(); ++j) {
             const Pick &q = picks[j];
-            if (done[j] || q.tw_log2 != cls.tw_log2 || q.th != cls.th || q.lds != cls.lds || q.bucket != picks[k].bucket) continue;
+            if (done[j] || q.tw_log2 != cls.tw_log2 || q.th != cls.th || q.lds != cls.lds || q.bucket != picks[k].bucket || q.qb_div != cls.qb_div) continue;
             done[j] = 1;
             cls.dyn_lds = std::max(cls.dyn_lds, q.dyn);
             const ScaleDesc &sd = p.scales[j];
@@ -664,7 +669,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.tabp = p->d_tabp.p;
     a.codes = c->d_codes.p;
     a.late_waves = std::max(1, std::min(kLateWaves, env_int("PIGO_LATE_WAVES", kLateWaves)));
-    a.qb_div = p->rot ? 1 : 2;
+    a.qb_div = 2;  // per class, see build_tile_classes
     a.stats = nullptr;
     if (env_int("PIGO_DEBUG_STATS", 0)) {
         HIP_TRY(p->d_stats.alloc(65536 * 8 + 16 * 256 + 256 * 8));
@@ -729,6 +734,7 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             ca.th = cls.th;
             ca.nwin = cls.nwin;
             ca.tab_trees = cls.lds ? p.tab_lds : p.tab_glb;
+            ca.qb_div = cls.qb_div;
             const uint32_t grid = (uint32_t)a.nframes * cls.ntiles;
             mark(cls.lds ? "scan_tile_lds" : "scan_tile_glb");
             const bool wide = p.tile_threads == 512;

@@ -7,6 +7,8 @@ timeout 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_
 timeout 300 python bench.py --force-dist --frames 32 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_dist1.json 2> gpurun_out/bench_dist1.err; echo "dist1 rc=$?"; cut -c1-300 gpurun_out/bench_dist1.json; tail -3 gpurun_out/bench_dist1.err
 timeout 300 python bench.py --kind noise --no-cpu-baseline > gpurun_out/bench_noise.json 2> gpurun_out/bench_noise.err; echo "noise rc=$?"; cut -c1-400 gpurun_out/bench_noise.json
 timeout 300 python bench.py --angle 0.8 --no-cpu-baseline > gpurun_out/bench_rot.json 2> gpurun_out/bench_rot.err; echo "rot rc=$?"; cut -c1-400 gpurun_out/bench_rot.json
+timeout 300 python bench.py --rows 2160 --cols 3840 --min-size 20 --max-size 2000 --shift 0.05 --scale 1.05 --frames 8 --det-cap 32768 --gather-cap 64 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_4k.json 2> gpurun_out/bench_4k.err; echo "4k rc=$?"; cut -c1-400 gpurun_out/bench_4k.json; tail -2 gpurun_out/bench_4k.err
+python scripts/single_frame_latency.py 2>&1 | grep "single 1080p" | tee gpurun_out/single_frame.txt
 B="python bench.py --frames 64 --steps 5 --warmup 2 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r1f/trace -o t -- $B > gpurun_out/prof_r1f/trace.log 2>&1; echo "trace rc=$?"
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_r1f/pmc_fetch -o p -- $B > gpurun_out/prof_r1f/pmc_fetch.log 2>&1; echo "pmc_fetch rc=$?"

@@ -277,7 +277,9 @@ def test_4k_config5_variants_agree_and_match_oracle(pg, orc):
         plan.set_variant(variant)
         assert plan.info().windows_per_frame == 113382193 and plan.info().n_scales == 96
         dets, counts = plan.alloc_outputs(1)
-        plan.run(d_frames, dets, counts, sync=True)
+        plan.run(d_frames, dets, counts)
+        torch.cuda.synchronize()
+        plan.status()  # no queue overflow, i.e. no silent trip through the monolithic fallback, on the step-1 scales
         res[variant] = batch.dets_to_numpy(dets, counts, 0)
     assert_same_dets(res[1], res[0], "4K v1 vs v0", Q_TOL_RAW)
     assert_same_dets(res[2], res[0], "4K v2 vs v0", Q_TOL_RAW)
