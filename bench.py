@@ -208,6 +208,13 @@ def main():
         dom = {2: "scan_tile+tail_deep", 1: "scan_head+scan_tail", 0: "scan_mono"}.get(int(info.variant), "scan")
         alg_bytes = B * args.rows * args.cols + 16 * ndet  # every frame read once + 16 B per emitted detection
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms else None
+        # HBM traffic: PMC counters cannot be read live; the committed profile of the same workload (separate rocprofv3
+        # --pmc passes, profiles/r01_traffic.json) gives bytes per frame, scaled here to this batch
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and (args.rows, args.cols, args.kind, args.angle) == (1080, 1920, "faces", 0.0) and int(info.variant) == 2:
+            with open(tpath) as fh:
+                traffic = int(json.load(fh)["hbm_bytes_per_frame"]) * B
         out = {
             "metric": "Mwindows/s (1080p facefinder scan, shift 0.1 / scale 1.1)" if (args.rows, args.cols) == (1080, 1920) else "Mwindows/s",
             "value": round(fps * wpf / 1e6, 3),
@@ -234,7 +241,8 @@ def main():
                 "bound": "hbm", "kernel": "k_" + dom, "kernel_ms_per_batch": round(scan_ms, 4),
                 "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": "profiled offline (profiles/r01_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE per frame x frames); dominated by the deep tail's footprint copies" if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "compulsory bytes only (each frame read once); the kernel is gather/issue bound, see DESIGN.md",
             },
