@@ -14,6 +14,7 @@ Rank 0 prints ONE JSON line (see the task contract) with two extra objects:
   roofline      HBM roofline of the dominant kernel (k_scan_head): algorithmic bytes per launch (every frame
                 read once + 16 B per detection) / that kernel's mean duration measured with HIP events on the
                 launch stream; peak 8.0 TB/s.
+  gray          side measurement of the RgbToGrayscale kernel (the streaming step in front of the scan): GB/s vs 8 TB/s.
   cpu_baseline  the CPU oracle (a C restatement of the reference's Go path -- the Go toolchain is absent) timed
                 on this host's cores on a bounded sample of the same frames.
 """
@@ -54,6 +55,7 @@ def parse_args():
     ap.add_argument("--no-cluster", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gray", action="store_true", help="skip the RgbToGrayscale (row f1) side measurement")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto, ~15 s)")
     return ap.parse_args()
 
@@ -197,6 +199,31 @@ def main():
         torch.cuda.synchronize()
         cluster_ms = cev[0].elapsed_time(cev[1]) / reps
 
+    # ---- side measurement, outside the timed region: RgbToGrayscale (core/grayscale.go:8-23), the streaming step in
+    # front of the scan.  RGBA frames {g,g,g,255} built on the GPU from the gray batch; the kernel must give them back.
+    gray_leg = None
+    if rank == 0 and not args.no_gray:
+        gn = min(B, 64)
+        rgba = torch.empty((gn, args.rows, args.cols, 4), dtype=torch.uint8, device=dev)
+        rgba[..., :3] = d_frames[:gn].unsqueeze(-1)
+        rgba[..., 3] = 255
+        gout = torch.zeros((gn, args.rows, args.cols), dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            batch.rgb_to_grayscale(rgba, kind=core.PIX_NRGBA, out=gout)
+        gev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        greps = 20
+        gev[0].record()
+        for _ in range(greps):
+            batch.rgb_to_grayscale(rgba, kind=core.PIX_NRGBA, out=gout)  # launched on torch's current stream
+        gev[1].record()
+        torch.cuda.synchronize()
+        gms = gev[0].elapsed_time(gev[1]) / greps
+        gbytes = gn * args.rows * args.cols * 5  # 4 B read + 1 B written per pixel
+        gray_leg = {"kernel": "k_rgb_to_gray_lin<NRGBA>", "frames": gn, "ms_per_launch": round(gms, 4), "bytes_per_launch": gbytes,
+                    "bound": "hbm", "achieved": round(gbytes / (gms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbytes / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "roundtrip_ok": bool(torch.equal(gout, d_frames[:gn]))}
+        del rgba, gout
+
     if rank == 0:
         wpf = int(info.windows_per_frame)
         total_frames = n_gpus * B * args.steps
@@ -247,6 +274,7 @@ def main():
                 "note": "compulsory bytes only (each frame read once); the kernel is gather/issue bound, see DESIGN.md",
             },
         }
+        out["gray"] = gray_leg
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, frames, wpf)
         else:

@@ -137,6 +137,25 @@ private:
     std::shared_ptr<pigo_cascade> h_;  // immutable after Unpack, shareable between threads like the Go struct
 };
 
+// The pixel buffer of a Go image (image.NRGBA / image.RGBA: Pix, Stride, Rect), as RgbToGrayscale's argument
+struct Image {
+    const std::vector<uint8_t> *Pix = nullptr;  // {R,G,B,A} bytes, row-major, pixel (0,0) first
+    int Stride = 0, Width = 0, Height = 0;
+    int Kind = PIGO_PIX_NRGBA;                  // PIGO_PIX_NRGBA (GetImage's result) | PIGO_PIX_RGBA | PIGO_PIX_CANVAS
+};
+
+// RgbToGrayscale, core/grayscale.go:8-23
+inline std::vector<uint8_t> RgbToGrayscale(const Image &src, int device = 0)
+{
+    std::vector<uint8_t> gray((size_t)src.Width * (size_t)src.Height);
+    if (gray.empty()) return gray;
+    if (!src.Pix) throw std::invalid_argument("RgbToGrayscale: Image.Pix is null");
+    detail::check(pigo_rgb_to_grayscale(device, src.Pix->data(), src.Pix->size(), src.Width, src.Height, src.Stride, src.Kind, gray.data(),
+                                        gray.size()),
+                  "RgbToGrayscale");
+    return gray;
+}
+
 // NewPigo, core/pigo.go:46
 inline Pigo NewPigo(int device = 0) { return Pigo(device); }
 

@@ -91,6 +91,27 @@ pigo_status pigo_cluster_detections(pigo_cascade *c, pigo_det *dets, int n, doub
 /* The sort step alone (host): sort.Slice(dets, func(i, j) bool { return dets[i].Q < dets[j].Q }), pigo.go:264 */
 void pigo_sort_by_q(pigo_det *dets, int n);
 
+/* ---- RgbToGrayscale, core/grayscale.go:8-23 (the step in front of RunCascade) ---------------------
+ * `pix` is the Pix buffer of the image the reference would be handed: `height` rows of `stride`
+ * bytes, 4 bytes {R,G,B,A} per pixel, pixel (0,0) first.  `kind` says how src.At(x,y).RGBA()
+ * (grayscale.go:14) reads it:
+ *   PIGO_PIX_NRGBA  *image.NRGBA, what GetImage/DecodeImage return (core/image.go:12-90): c*0x101*A/0xff
+ *   PIGO_PIX_RGBA   *image.RGBA  (core/grayscale_test.go:15): c*0x101
+ *   PIGO_PIX_CANVAS the wasm front end's own formula on raw canvas RGBA (wasm/canvas/canvas.go:179-191)
+ * gray[y*width + x] = uint8((0.299 r + 0.587 g + 0.114 b) / 256) in float64, bit-exact.
+ * PIGO_ERR_PANIC when Pix is too short for (width, height, stride) -- src.At would index past it;
+ * PIGO_ERR_CAPACITY when `cap` < width*height. */
+#define PIGO_PIX_NRGBA 0
+#define PIGO_PIX_RGBA 1
+#define PIGO_PIX_CANVAS 2
+pigo_status pigo_rgb_to_grayscale(int device, const uint8_t *pix, size_t npix, int width, int height, int stride, int kind,
+                                  uint8_t *gray, size_t cap);
+/* Device-resident batch form (extension): `nframes` frames of `frame_stride` bytes in device memory
+ * -> gray frames of `gray_frame_stride` bytes with rows of `gray_dim` >= width bytes (ImageParams.Dim),
+ * enqueued on `stream` (hipStream_t, NULL = default).  The output can be fed to pigo_plan_run as is. */
+pigo_status pigo_gray_batch(int device, const uint8_t *d_pix, size_t frame_stride, int stride, int width, int height, int kind,
+                            int nframes, uint8_t *d_gray, size_t gray_frame_stride, int gray_dim, void *stream);
+
 /* ---- batch / device-resident extension (BASELINE configs 2-5; no reference counterpart) ----------
  * A plan fixes (rows, cols, dim, MinSize, MaxSize, ShiftFactor, ScaleFactor, angle) and owns the
  * workspace for up to `max_frames` frames with up to `det_cap` raw detections per frame. */

@@ -69,6 +69,8 @@ def lib():
         L.oracle_calc_iou.restype = dbl
         L.oracle_cluster_detections.argtypes = [vp, ll, dbl, vp, C.POINTER(ll)]
         L.oracle_cluster_detections.restype = ll
+        L.oracle_rgb_to_grayscale.argtypes = [vp, ll, ll, ll, C.c_int, vp]
+        L.oracle_rgb_to_grayscale.restype = C.c_int
         _lib = L
     return _lib
 
@@ -181,3 +183,20 @@ def make_dets(rows):
     for i, (r, c, s, q) in enumerate(rows):
         a[i] = (r, c, s, q)
     return a
+
+
+#: pixel kinds of rgb_to_grayscale: *image.NRGBA, *image.RGBA, the wasm canvas variant
+PIX_NRGBA, PIX_RGBA, PIX_CANVAS = 0, 1, 2
+
+
+def rgb_to_grayscale(pix, kind=PIX_NRGBA):
+    """RgbToGrayscale (core/grayscale.go:8-23) on an (H, W, 4) uint8 array whose rows may be strided."""
+    pix = np.asarray(pix, dtype=np.uint8)
+    assert pix.ndim == 3 and pix.shape[2] == 4 and pix.strides[2] == 1 and pix.strides[1] == 4
+    h, w = pix.shape[:2]
+    out = np.zeros(h * w, dtype=np.uint8)
+    if h and w:
+        rc = lib().oracle_rgb_to_grayscale(pix.ctypes.data, w, h, pix.strides[0], kind, out.ctypes.data)
+        if rc != 0:
+            raise ValueError("unknown pixel kind %r" % (kind,))
+    return out

@@ -151,3 +151,26 @@ class NpPigo:
             if cnt > 0:
                 clusters.append((r // cnt, c // cnt, s // cnt, q))
         return d, clusters
+
+
+def np_rgb_to_grayscale(pix, kind=0):
+    """Independent vectorised restatement of RgbToGrayscale (core/grayscale.go:8-23; kind 2: wasm/canvas/canvas.go:179-191).
+
+    kind 0: *image.NRGBA (color.NRGBA.RGBA(): c*0x101*A/0xff), kind 1: *image.RGBA (c*0x101).  float64, left to right.
+    """
+    pix = np.asarray(pix, dtype=np.uint8)
+    h, w = pix.shape[:2]
+    ch = pix.astype(np.uint32)
+    if kind == 2:
+        v = np.float64(0.2126) * ch[..., 0].astype(np.float64) + np.float64(0.7152) * ch[..., 1].astype(np.float64)
+        v = v + np.float64(0.0722) * ch[..., 2].astype(np.float64)
+        r = np.where(v >= 0, np.floor(v), np.ceil(v))          # math.Round: truncate, then step away from zero at >= .5
+        r = np.where(np.abs(v - r) >= 0.5, r + np.sign(v), r)
+        return r.astype(np.uint8).reshape(h * w)
+    c16 = ch[..., :3] * np.uint32(0x101)
+    if kind == 0:
+        c16 = (c16 * ch[..., 3:4]) // np.uint32(0xff)
+    f = c16.astype(np.float64)
+    v = np.float64(0.299) * f[..., 0] + np.float64(0.587) * f[..., 1]
+    v = v + np.float64(0.114) * f[..., 2]
+    return np.trunc(v / 256).astype(np.uint8).reshape(h * w)

@@ -683,3 +683,59 @@ gint oracle_cluster_detections(oracle_det *detections, gint n, double iou_thresh
     free(assignments);
     return nclusters;
 }
+
+/* ======================================================================================================
+ * RgbToGrayscale  (the step immediately before RunCascade)
+ *
+ *     RgbToGrayscale              /root/reference/core/grayscale.go:8-23
+ *     (*Canvas).rgbaToGrayscale   /root/reference/wasm/canvas/canvas.go:179-191   (kind 2)
+ *
+ * The reference calls src.At(x, y).RGBA() (grayscale.go:14), which is Go standard-library code that is
+ * NOT under /root/reference: package image/color (go 1.22, go.mod:3).  Its published behaviour, restated:
+ *     color.NRGBA.RGBA():  r = R; r |= r << 8; r *= A; r /= 0xff   (uint32; same for g, b)   -> kind 0
+ *     color.RGBA.RGBA():   r = R; r |= r << 8                      (already premultiplied)   -> kind 1
+ * GetImage / DecodeImage hand the CLI an *image.NRGBA (core/image.go:12-90), the reference's own test builds
+ * an *image.RGBA (core/grayscale_test.go:15).  The mix is evaluated in float64, left to right, unfused
+ * (Go/amd64, GOAMD64=v1), and uint8() of a float64 truncates toward zero (grayscale.go:15-19).
+ *
+ * PARITY UNPINNED like the rest of this file (no Go toolchain); pinned by the one known answer the
+ * reference's test implies (R=G=B=v, A=255 gives v; core/grayscale_test.go:14-34) and the NumPy restatement.
+ * ====================================================================================================== */
+#define ORACLE_PIX_NRGBA 0
+#define ORACLE_PIX_RGBA 1
+#define ORACLE_PIX_CANVAS 2
+
+static uint32_t go_rgba16(uint32_t c8, uint32_t a8, int kind)
+{
+    uint32_t r = c8;
+    r |= r << 8;
+    if (kind == ORACLE_PIX_NRGBA) {
+        r *= a8;
+        r /= 0xff;
+    }
+    return r;
+}
+
+/* pix: rows of `stride` bytes, 4 bytes {R,G,B,A} per pixel; out: width*height bytes, out[y*width + x]
+ * (grayscale.go:10,15).  Returns 0, or -1 for an unknown kind. */
+int oracle_rgb_to_grayscale(const uint8_t *pix, gint width, gint height, gint stride, int kind, uint8_t *out)
+{
+    if (kind < 0 || kind > 2) return -1;
+    for (gint y = 0; y < height; y++) {          /* grayscale.go:12 */
+        for (gint x = 0; x < width; x++) {       /* grayscale.go:13 */
+            const uint8_t *p = pix + y * stride + 4 * x;
+            if (kind == ORACLE_PIX_CANVAS) {
+                /* canvas.go:184-187: uint8(math.Round(0.2126*R + 0.7152*G + 0.0722*B)); alpha ignored */
+                double v = 0.2126 * (double)p[0] + 0.7152 * (double)p[1];
+                v = v + 0.0722 * (double)p[2];
+                out[y * width + x] = (uint8_t)round(v); /* math.Round: half away from zero, like C round() */
+                continue;
+            }
+            const uint32_t r = go_rgba16(p[0], p[3], kind), g = go_rgba16(p[1], p[3], kind), b = go_rgba16(p[2], p[3], kind);
+            double v = 0.299 * (double)r + 0.587 * (double)g; /* grayscale.go:16-17 */
+            v = v + 0.114 * (double)b;                         /* grayscale.go:18 */
+            out[y * width + x] = (uint8_t)(v / 256);           /* grayscale.go:15,19: truncation */
+        }
+    }
+    return 0;
+}

@@ -127,3 +127,23 @@ def dets_to_numpy(dets, counts, frame=None):
         n = min(int(c[f]), cap)
         out.append(np.ascontiguousarray(d[f, :n]).view(core.DET_DTYPE).reshape(n).copy())
     return out if frame is None else out[frame]
+
+
+def rgb_to_grayscale(rgba, kind=core.PIX_NRGBA, out=None, dim=None, stream=None):
+    """RgbToGrayscale (core/grayscale.go:8-23) over a batch of device-resident frames.
+
+    rgba: uint8 [n, rows, cols, 4] {R,G,B,A} on the GPU (contiguous); returns uint8 [n, rows, dim] gray frames
+    (dim >= cols, default cols) that ``ScanPlan.run`` takes as is.  Enqueued on the current stream, nothing synchronised.
+    """
+    torch = _torch()
+    assert rgba.dtype == torch.uint8 and rgba.is_cuda and rgba.is_contiguous() and rgba.dim() == 4 and rgba.shape[3] == 4, rgba.shape
+    n, rows, cols = (int(v) for v in rgba.shape[:3])
+    dim = cols if dim is None else int(dim)
+    if out is None:
+        out = torch.zeros((n, rows, dim), dtype=torch.uint8, device=rgba.device)
+    assert out.dtype == torch.uint8 and out.is_cuda and out.is_contiguous() and tuple(out.shape) == (n, rows, dim), out.shape
+    L = core.load_library()
+    dev = rgba.device.index if rgba.device.index is not None else torch.cuda.current_device()
+    core.check(L.pigo_gray_batch(dev, C.c_void_p(rgba.data_ptr()), rows * cols * 4, cols * 4, cols, rows, int(kind), n,
+                                 C.c_void_p(out.data_ptr()), rows * dim, dim, ScanPlan._stream_ptr(stream)), "gray_batch")
+    return out

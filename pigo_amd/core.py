@@ -24,6 +24,9 @@ from . import build as _build
 #: Detection, core/pigo.go:195-200 -- the 16-byte wire record of the C ABI (pigo_det)
 DET_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("scale", "<i4"), ("q", "<f4")])
 
+#: how RgbToGrayscale reads the 4-byte pixels: *image.NRGBA, *image.RGBA, the wasm canvas formula (include/pigo_hip.h)
+PIX_NRGBA, PIX_RGBA, PIX_CANVAS = 0, 1, 2
+
 PIGO_OK, ERR_PACKET, ERR_PARAM, ERR_HIP, ERR_CAPACITY, ERR_PANIC, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 
 
@@ -47,6 +50,7 @@ ABI_SYMBOLS = [
     "pigo_run_cascade", "pigo_cluster_detections", "pigo_sort_by_q", "pigo_plan_create", "pigo_plan_destroy", "pigo_plan_info",
     "pigo_plan_set_variant", "pigo_plan_run", "pigo_plan_cluster", "pigo_plan_status", "pigo_plan_run_sync", "pigo_plan_set_profiling",
     "pigo_plan_last_timings", "pigo_plan_last_queue_count", "pigo_plan_debug_stats", "pigo_plan_debug_trace",
+    "pigo_rgb_to_grayscale", "pigo_gray_batch",
 ]
 
 _lib = None
@@ -92,6 +96,8 @@ def load_library():
     L.pigo_plan_last_queue_count.argtypes = [vp, C.POINTER(C.c_int64)]
     L.pigo_plan_debug_stats.argtypes = [vp, C.POINTER(C.c_uint64), i32]
     L.pigo_plan_debug_trace.argtypes = [vp, C.POINTER(C.c_uint64), i32]
+    L.pigo_rgb_to_grayscale.argtypes = [i32, vp, sz, i32, i32, i32, i32, vp, sz]
+    L.pigo_gray_batch.argtypes = [i32, vp, sz, i32, i32, i32, i32, i32, vp, sz, i32, vp]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("pigo_device_count", "pigo_plan_last_timings"):
@@ -231,3 +237,26 @@ class Pigo:
 def NewPigo(device: int = 0) -> Pigo:
     """core/pigo.go:46"""
     return Pigo(device=device)
+
+
+def RgbToGrayscale(src: np.ndarray, kind: int = PIX_NRGBA, device: int = 0) -> np.ndarray:
+    """core/grayscale.go:8-23 -- ``src`` is the image's Pix as an (H, W, 4) uint8 array {R,G,B,A} (rows may be strided,
+    like a Go sub-image); returns the width*height gray bytes RunCascade takes as ImageParams.Pixels.
+
+    ``kind`` names the Go image type the reference would have been handed (PIX_NRGBA: what GetImage returns;
+    PIX_RGBA: premultiplied) or PIX_CANVAS for the wasm front end's formula (wasm/canvas/canvas.go:179-191).
+    """
+    src = np.asarray(src)
+    if src.dtype != np.uint8 or src.ndim != 3 or src.shape[2] != 4:
+        raise ValueError("src must be an (H, W, 4) uint8 array")
+    h, w = src.shape[:2]
+    if h and w and (src.strides[2] != 1 or src.strides[1] != 4 or src.strides[0] < 4 * w):
+        src = np.ascontiguousarray(src)
+    out = np.zeros(h * w, dtype=np.uint8)
+    if h == 0 or w == 0:
+        return out
+    stride = src.strides[0]
+    npix = (h - 1) * stride + 4 * w
+    check(load_library().pigo_rgb_to_grayscale(int(device), src.ctypes.data, npix, w, h, stride, int(kind), out.ctypes.data, out.size),
+          "RgbToGrayscale")
+    return out

@@ -1351,3 +1351,78 @@ extern "C" pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, 
     }
     return fail(PIGO_ERR_CAPACITY, "RunCascade: detection count kept growing");
 }
+
+// ---- RgbToGrayscale (core/grayscale.go:8-23) ---------------------------------------------------------------------------
+
+namespace {
+
+template <int KIND>
+pigo_status launch_gray(const uint8_t *d_pix, size_t frame_stride, int stride, int width, int height, int nframes, uint8_t *d_gray,
+                        size_t gray_frame_stride, int gray_dim, hipStream_t stream)
+{
+    const size_t npx = (size_t)width * (size_t)height;
+    const bool lin = stride == 4 * width && gray_dim == width && npx % 4 == 0 && npx / 4 <= 0xffffffffull && frame_stride % 16 == 0 &&
+                     gray_frame_stride % 4 == 0 && ((uintptr_t)d_pix % 16) == 0 && ((uintptr_t)d_gray % 4) == 0;
+    if (lin) {
+        const uint32_t n4 = (uint32_t)(npx / 4);
+        const uint32_t per_block = (uint32_t)(kGrayThreads * kGrayQuads);
+        dim3 grid((n4 + per_block - 1) / per_block, (unsigned)nframes, 1);
+        hipLaunchKernelGGL((k_rgb_to_gray_lin<KIND>), grid, dim3(kGrayThreads), 0, stream, d_pix, frame_stride, d_gray, gray_frame_stride, n4);
+    } else {
+        dim3 grid((unsigned)((width + kGrayThreads - 1) / kGrayThreads), (unsigned)height, (unsigned)nframes);
+        hipLaunchKernelGGL((k_rgb_to_gray_gen<KIND>), grid, dim3(kGrayThreads), 0, stream, d_pix, frame_stride, stride, width, d_gray,
+                           gray_frame_stride, gray_dim);
+    }
+    HIP_TRY(hipGetLastError());
+    return PIGO_OK;
+}
+
+}  // namespace
+
+extern "C" pigo_status pigo_gray_batch(int device, const uint8_t *d_pix, size_t frame_stride, int stride, int width, int height, int kind,
+                                       int nframes, uint8_t *d_gray, size_t gray_frame_stride, int gray_dim, void *stream)
+{
+    if (kind < PIGO_PIX_NRGBA || kind > PIGO_PIX_CANVAS) return fail(PIGO_ERR_PARAM, "unknown pixel kind %d", kind);
+    if (width < 0 || height < 0 || nframes < 0) return fail(PIGO_ERR_PARAM, "negative width/height/nframes");
+    if (width >= 65536 * kGrayThreads || height >= 65536 || nframes >= 65536)
+        return fail(PIGO_ERR_PARAM, "width/height/nframes too large (%d, %d, %d)", width, height, nframes);
+    if (width == 0 || height == 0 || nframes == 0) return PIGO_OK;
+    if (!d_pix || !d_gray) return fail(PIGO_ERR_PARAM, "NULL device pointer");
+    if ((long long)stride < 4ll * width) return fail(PIGO_ERR_PARAM, "stride=%d < 4*width=%lld", stride, 4ll * width);
+    if (gray_dim < width) return fail(PIGO_ERR_PARAM, "gray_dim=%d < width=%d", gray_dim, width);
+    const size_t need_src = (size_t)(height - 1) * (size_t)stride + 4u * (size_t)width;
+    const size_t need_dst = (size_t)(height - 1) * (size_t)gray_dim + (size_t)width;
+    if (nframes > 1 && (frame_stride < need_src || gray_frame_stride < need_dst))
+        return fail(PIGO_ERR_PARAM, "frame strides (%zu, %zu) smaller than a frame (%zu, %zu)", frame_stride, gray_frame_stride, need_src,
+                    need_dst);
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    switch (kind) {
+    case PIGO_PIX_NRGBA: return launch_gray<0>(d_pix, frame_stride, stride, width, height, nframes, d_gray, gray_frame_stride, gray_dim, st);
+    case PIGO_PIX_RGBA: return launch_gray<1>(d_pix, frame_stride, stride, width, height, nframes, d_gray, gray_frame_stride, gray_dim, st);
+    default: return launch_gray<2>(d_pix, frame_stride, stride, width, height, nframes, d_gray, gray_frame_stride, gray_dim, st);
+    }
+}
+
+extern "C" pigo_status pigo_rgb_to_grayscale(int device, const uint8_t *pix, size_t npix, int width, int height, int stride, int kind,
+                                             uint8_t *gray, size_t cap)
+{
+    if (kind < PIGO_PIX_NRGBA || kind > PIGO_PIX_CANVAS) return fail(PIGO_ERR_PARAM, "unknown pixel kind %d", kind);
+    if (width < 0 || height < 0) return fail(PIGO_ERR_PARAM, "negative width/height");
+    const size_t npx = (size_t)width * (size_t)height;
+    if (npx == 0) return PIGO_OK;  // make([]uint8, 0)
+    if ((long long)stride < 4ll * width) return fail(PIGO_ERR_PARAM, "stride=%d < 4*width=%lld", stride, 4ll * width);
+    const size_t need = (size_t)(height - 1) * (size_t)stride + 4u * (size_t)width;
+    if (!pix || npix < need)  // src.At(x, y) indexes Pix past its end: the reference panics (grayscale.go:14)
+        return fail(PIGO_ERR_PANIC, "len(Pix)=%zu < %zu needed for %dx%d, stride %d", pix ? npix : (size_t)0, need, width, height, stride);
+    if (!gray || cap < npx) return fail(PIGO_ERR_CAPACITY, "gray buffer holds %zu bytes, %zu needed", gray ? cap : (size_t)0, npx);
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<uint8_t> d_src, d_dst;
+    if (d_src.alloc((need + 15) & ~(size_t)15) != hipSuccess || d_dst.alloc((npx + 3) & ~(size_t)3) != hipSuccess)
+        return fail(PIGO_ERR_NOMEM, "hipMalloc of %zu + %zu bytes failed", need, npx);
+    HIP_TRY(hipMemcpy(d_src.p, pix, need, hipMemcpyHostToDevice));
+    pigo_status st = pigo_gray_batch(device, d_src.p, need, stride, width, height, kind, 1, d_dst.p, npx, width, nullptr);
+    if (st != PIGO_OK) return st;
+    HIP_TRY(hipMemcpy(gray, d_dst.p, npx, hipMemcpyDeviceToHost));  // synchronises with the null stream
+    return PIGO_OK;
+}

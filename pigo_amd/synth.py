@@ -89,3 +89,12 @@ def make_frames(kind: str, n: int, rows: int, cols: int, seed: int = 1234, first
     for f in range(n):
         out[f] = gen(rows, cols, seed, first_index + f)
     return out
+
+
+def syn_rgba(rows: int, cols: int, seed: int = 1234, frame_index: int = 0, opaque_rows: int = None) -> np.ndarray:
+    """Seeded {R,G,B,A} test frame [rows, cols, 4] for RgbToGrayscale (core/grayscale.go:8-23): uniform random bytes;
+    the first ``opaque_rows`` rows (default: all) get A=255 like a decoded JPEG, the rest keep their random alpha."""
+    a = syn_noise(rows, cols * 4, seed=seed ^ 0x5A5A, frame_index=frame_index).reshape(rows, cols, 4).copy()
+    k = rows if opaque_rows is None else opaque_rows
+    a[:k, :, 3] = 255
+    return a

@@ -20,8 +20,14 @@ int main(int argc, char **argv)
         std::vector<pigo::Detection> cl = pg.ClusterDetections(dets, 0.1);
         std::printf("dets=%zu clusters=%zu", dets.size(), cl.size());
         for (const auto &c : cl) std::printf(" (%d,%d,%d,%.4f)", c.Row, c.Col, c.Scale, c.Q);
-        std::printf("\n");
-        return cl.empty() ? 1 : 0;
+        // core/grayscale_test.go:14-34: a uniform (177,177,177,255) image stays 177
+        std::vector<uint8_t> pix(10 * 10 * 4, 177);
+        for (size_t i = 3; i < pix.size(); i += 4) pix[i] = 255;
+        const std::vector<uint8_t> g177 = pigo::RgbToGrayscale(pigo::Image{&pix, 40, 10, 10, PIGO_PIX_RGBA});
+        bool gray_ok = g177.size() == 100;
+        for (uint8_t v : g177) gray_ok = gray_ok && v == 177;
+        std::printf(" gray177=%d\n", gray_ok ? 1 : 0);
+        return cl.empty() || !gray_ok ? 1 : 0;
     } catch (const pigo::Panic &e) {
         std::printf("panic: %s\n", e.what());
         return 3;

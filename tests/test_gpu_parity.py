@@ -305,4 +305,4 @@ def test_cpp_mirror_runs_on_gpu(tmp_path):
                            "-o", exe, "-L" + csrc, "-lpigo_hip", "-Wl,-rpath," + csrc])
     r = subprocess.run([exe, os.path.join(root, "pigo_amd", "data", "facefinder"), os.path.join(root, "pigo_amd", "data", "sample_gray_320x400.bin")],
                        capture_output=True, text=True)
-    assert r.returncode == 0 and "dets=4 clusters=1 (206,154,261," in r.stdout, (r.returncode, r.stdout, r.stderr)
+    assert r.returncode == 0 and "dets=4 clusters=1 (206,154,261," in r.stdout and "gray177=1" in r.stdout, (r.returncode, r.stdout, r.stderr)
