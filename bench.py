@@ -14,6 +14,7 @@ Rank 0 prints ONE JSON line (see the task contract) with two extra objects:
   roofline      HBM roofline of the dominant kernel (k_scan_head): algorithmic bytes per launch (every frame
                 read once + 16 B per detection) / that kernel's mean duration measured with HIP events on the
                 launch stream; peak 8.0 TB/s.
+  puploc        side measurement of the RunDetector kernel (4096 requests x 63 perturbations): requests/s.
   gray          side measurement of the RgbToGrayscale kernel (the streaming step in front of the scan): GB/s vs 8 TB/s.
   cpu_baseline  the CPU oracle (a C restatement of the reference's Go path -- the Go toolchain is absent) timed
                 on this host's cores on a bounded sample of the same frames.
@@ -224,6 +225,45 @@ def main():
                     "frac": round(gbytes / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "roundtrip_ok": bool(torch.equal(gout, d_frames[:gn]))}
         del rgba, gout
 
+    # ---- side measurement: RunDetector (core/puploc.go:239-277), the step behind ClusterDetections.  4096 eye-sized
+    # requests with 63 perturbations each, spread over the resident frames; one launch, one workgroup per request.
+    pup_leg = None
+    if rank == 0 and not args.no_gray:
+        plc = core.NewPuplocCascade(local_rank).UnpackCascade(synth.cascade_bytes("puploc"))
+        nreq = 4096
+        rng = np.random.default_rng(args.seed)
+        reqs = np.zeros(nreq, dtype=core.PUPLOC_REQ_DTYPE)
+        reqs["row"], reqs["col"] = rng.integers(40, args.rows - 40, nreq), rng.integers(40, args.cols - 40, nreq)
+        reqs["scale"] = rng.uniform(10, 60, nreq).astype(np.float32)
+        reqs["perturbs"] = 63
+        reqs["frame"] = rng.integers(0, B, nreq)
+        rnd = rng.random((nreq, 189), dtype=np.float32)
+        d_reqs = torch.from_numpy(reqs.view(np.uint8).reshape(nreq, 24)).to(dev)
+        d_rnd = torch.from_numpy(rnd).to(dev)
+        pout = torch.zeros((nreq, 4), dtype=torch.int32, device=dev)
+        for _ in range(2):
+            batch.puploc_run_batch(plc, d_frames, d_reqs, d_rnd, out=pout)
+        pev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        preps = 10
+        pev[0].record()
+        for _ in range(preps):
+            batch.puploc_run_batch(plc, d_frames, d_reqs, d_rnd, out=pout)
+        pev[1].record()
+        torch.cuda.synchronize()
+        batch.puploc_status(plc)
+        pms = pev[0].elapsed_time(pev[1]) / preps
+        pup_leg = {"kernel": "k_puploc", "requests": nreq, "perturbs": 63, "ms_per_launch": round(pms, 4),
+                   "requests_per_s": round(nreq / (pms * 1e-3), 1), "tree_walks_per_s": round(nreq * 63 * 100 / (pms * 1e-3), 1)}
+        if not args.no_cpu_baseline:
+            import oracle
+            oplc = oracle.OraclePuploc.unpack(synth.cascade_bytes("puploc"))
+            t = time.perf_counter()
+            for i in range(40):
+                r = reqs[i]
+                oplc.run_detector(int(r["row"]), int(r["col"]), float(r["scale"]), 63, frames[r["frame"]], args.rows, args.cols, args.cols, 0.0,
+                                  False, rnd[i], None)
+            pup_leg["cpu_requests_per_s_one_thread"] = round(40 / (time.perf_counter() - t), 1)
+
     if rank == 0:
         wpf = int(info.windows_per_frame)
         total_frames = n_gpus * B * args.steps
@@ -275,6 +315,7 @@ def main():
             },
         }
         out["gray"] = gray_leg
+        out["puploc"] = pup_leg
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, frames, wpf)
         else:

@@ -17,6 +17,8 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <functional>
+#include <random>
 #include <vector>
 
 #include "pigo_hip.h"
@@ -155,6 +157,91 @@ inline std::vector<uint8_t> RgbToGrayscale(const Image &src, int device = 0)
                   "RgbToGrayscale");
     return gray;
 }
+
+// ---- pupil / facial-landmark localisation: core/puploc.go, core/flploc.go -----------------------------------------------
+
+// Puploc, core/puploc.go:14-19
+struct Puploc {
+    int Row = 0, Col = 0;
+    float Scale = 0.0f;
+    int Perturbs = 0;
+};
+
+// The two inputs of RunDetector that the reference takes from process-global state (see include/pigo_hip.h):
+// the rand.Float32() stream and the sync.Pool object.  A default-constructed DetectorState draws from std::mt19937 and
+// keeps one pool object, which is what a single-goroutine Go program sees.
+struct DetectorState {
+    std::function<float()> Float32;   // next value of the uniform [0,1) stream (rand.Float32(), puploc.go:248-250)
+    float Pool[3 * 63] = {0};         // rows | cols | scale of the sync.Pool object (puploc.go:228-237)
+    bool UsePool = true;              // false: every call sees a brand-new pool object
+};
+
+class PuplocCascade {
+public:
+    explicit PuplocCascade(int device = 0) : device_(device) {}
+
+    // UnpackCascade, core/puploc.go:38-103: returns a NEW cascade
+    PuplocCascade UnpackCascade(const std::vector<uint8_t> &packet) const
+    {
+        pigo_puploc_cascade *h = nullptr;
+        detail::check(pigo_puploc_create(packet.data(), packet.size(), device_, &h), "UnpackCascade");
+        PuplocCascade out(device_);
+        out.h_ = std::shared_ptr<pigo_puploc_cascade>(h, [](pigo_puploc_cascade *c) { pigo_puploc_destroy(c); });
+        return out;
+    }
+
+    // RunDetector, core/puploc.go:239-277
+    Puploc RunDetector(const Puploc &pl, const ImageParams &img, double angle, bool flipV, DetectorState &st) const
+    {
+        need();
+        if (!img.Pixels) throw std::invalid_argument("RunDetector: ImageParams.Pixels is null");
+        const std::vector<float> rnd = draw(pl.Perturbs, st);
+        const pigo_puploc in{pl.Row, pl.Col, pl.Scale, pl.Perturbs};
+        pigo_puploc out{};
+        detail::check(pigo_puploc_run_detector(h_.get(), &in, img.Pixels->data(), img.Pixels->size(), img.Rows, img.Cols, img.Dim, angle,
+                                               flipV ? 1 : 0, rnd.data(), st.UsePool ? st.Pool : nullptr, &out),
+                      "RunDetector");
+        return Puploc{out.row, out.col, out.scale, 0};
+    }
+
+    // GetLandmarkPoint, core/flploc.go:36-57
+    Puploc GetLandmarkPoint(const Puploc &leftEye, const Puploc &rightEye, const ImageParams &img, int perturb, bool flipV,
+                            DetectorState &st) const
+    {
+        need();
+        if (!img.Pixels) throw std::invalid_argument("GetLandmarkPoint: ImageParams.Pixels is null");
+        const std::vector<float> rnd = draw(perturb, st);
+        const pigo_puploc l{leftEye.Row, leftEye.Col, leftEye.Scale, 0}, r{rightEye.Row, rightEye.Col, rightEye.Scale, 0};
+        pigo_puploc out{};
+        detail::check(pigo_get_landmark_point(h_.get(), &l, &r, img.Pixels->data(), img.Pixels->size(), img.Rows, img.Cols, img.Dim, perturb,
+                                              flipV ? 1 : 0, rnd.data(), st.UsePool ? st.Pool : nullptr, &out),
+                      "GetLandmarkPoint");
+        return Puploc{out.row, out.col, out.scale, 0};
+    }
+
+    pigo_puploc_cascade *handle() const { return h_.get(); }  // for pigo_puploc_run_batch
+
+private:
+    static std::vector<float> draw(int perturbs, DetectorState &st)
+    {
+        std::vector<float> rnd(3 * (size_t)(perturbs > 0 ? perturbs : 0) + 3, 0.0f);
+        if (!st.Float32) {
+            auto gen = std::make_shared<std::mt19937>(std::random_device{}());
+            st.Float32 = [gen]() { return (float)((*gen)() >> 8) / 16777216.0f; };
+        }
+        for (int i = 0; i < 3 * perturbs && i < 3 * 64; ++i) rnd[(size_t)i] = st.Float32();  // row, col, scale of perturbation 0, 1, ...
+        return rnd;
+    }
+    void need() const
+    {
+        if (!h_) throw std::runtime_error("PuplocCascade is not unpacked (call UnpackCascade first)");
+    }
+    int device_ = 0;
+    std::shared_ptr<pigo_puploc_cascade> h_;
+};
+
+// NewPuplocCascade, core/puploc.go:32-34
+inline PuplocCascade NewPuplocCascade(int device = 0) { return PuplocCascade(device); }
 
 // NewPigo, core/pigo.go:46
 inline Pigo NewPigo(int device = 0) { return Pigo(device); }

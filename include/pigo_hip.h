@@ -112,6 +112,53 @@ pigo_status pigo_rgb_to_grayscale(int device, const uint8_t *pix, size_t npix, i
 pigo_status pigo_gray_batch(int device, const uint8_t *d_pix, size_t frame_stride, int stride, int width, int height, int kind,
                             int nframes, uint8_t *d_gray, size_t gray_frame_stride, int gray_dim, void *stream);
 
+/* ---- PuplocCascade: pupil / facial-landmark localisation, core/puploc.go + core/flploc.go ---------
+ * The step behind ClusterDetections for every face with Scale > 50 (cmd/pigo/main.go:404-564).
+ *
+ * Two inputs of RunDetector are not among the reference's arguments and are made explicit here:
+ *   rnd   the 3*Perturbs float32 values rand.Float32() returns inside RunDetector (puploc.go:248-250),
+ *         in draw order: row, col, scale of perturbation 0, then of perturbation 1, ...  The Go shim
+ *         draws them from math/rand exactly as the reference would, so results match for any seed.
+ *   pool  the sync.Pool object's three 63-entry arrays rows|cols|scale (puploc.go:228-237), 189
+ *         floats, read AND written: the reference never clears them and sorts all 63 entries
+ *         (puploc.go:267-269), so with Perturbs < 63 its result depends on what the previous user of
+ *         the pool object left behind.  NULL = a brand-new object (zeros).  The shim keeps these in
+ *         a sync.Pool of its own, which reproduces the reference's behaviour call for call. */
+typedef struct pigo_puploc_cascade pigo_puploc_cascade;
+/* Puploc, core/puploc.go:14-19 (Go: Row, Col int; Scale float32; Perturbs int) */
+typedef struct {
+    int32_t row, col;
+    float scale;
+    int32_t perturbs;
+} pigo_puploc;
+/* UnpackCascade, core/puploc.go:38-103 (UnpackFlp, core/flploc.go:27-33, is ReadFile + this).  Wire format:
+ * {stages u32, scale f32, trees u32, depth u32} then per tree 4*2^depth-4 code bytes + 2*2^depth float32.
+ * PIGO_ERR_PACKET where the reference panics on a short packet. */
+pigo_status pigo_puploc_create(const uint8_t *packet, size_t len, int device, pigo_puploc_cascade **out);
+pigo_status pigo_puploc_info(const pigo_puploc_cascade *c, uint32_t *stages, float *scales, uint32_t *trees, uint32_t *tree_depth);
+void pigo_puploc_destroy(pigo_puploc_cascade *c);
+/* RunDetector, core/puploc.go:239-277.  PIGO_ERR_PANIC where the reference panics: Perturbs outside
+ * [0, 63], rows/cols < 1, pixels shorter than (rows-1)*dim+cols. */
+pigo_status pigo_puploc_run_detector(pigo_puploc_cascade *c, const pigo_puploc *pl, const uint8_t *pixels, size_t npixels, int rows,
+                                     int cols, int dim, double angle, int flip_v, const float *rnd, float *pool, pigo_puploc *out);
+/* GetLandmarkPoint, core/flploc.go:36-57 */
+pigo_status pigo_get_landmark_point(pigo_puploc_cascade *c, const pigo_puploc *left_eye, const pigo_puploc *right_eye,
+                                    const uint8_t *pixels, size_t npixels, int rows, int cols, int dim, int perturb, int flip_v,
+                                    const float *rnd, float *pool, pigo_puploc *out);
+/* Device-resident batch form (extension): n independent RunDetector requests against `nframes` gray
+ * frames in device memory, one workgroup per request, enqueued on `stream`.  d_rnd: [n][189] floats
+ * (request q, perturbation p uses d_rnd[q*189 + 3p .. +2]); d_pool: [n][189] in/out or NULL (fresh).
+ * pigo_puploc_status() after synchronising reports a request the reference would have panicked on. */
+typedef struct {
+    int32_t row, col;
+    float scale;
+    int32_t perturbs, frame, flip_v;
+} pigo_puploc_req;
+pigo_status pigo_puploc_run_batch(pigo_puploc_cascade *c, const uint8_t *d_frames, size_t frame_stride, int nframes, int rows, int cols,
+                                  int dim, double angle, const pigo_puploc_req *d_reqs, const float *d_rnd, float *d_pool, int n,
+                                  pigo_puploc *d_out, void *stream);
+pigo_status pigo_puploc_status(pigo_puploc_cascade *c);
+
 /* ---- batch / device-resident extension (BASELINE configs 2-5; no reference counterpart) ----------
  * A plan fixes (rows, cols, dim, MinSize, MaxSize, ShiftFactor, ScaleFactor, angle) and owns the
  * workspace for up to `max_frames` frames with up to `det_cap` raw detections per frame. */

@@ -71,6 +71,21 @@ def lib():
         L.oracle_cluster_detections.restype = ll
         L.oracle_rgb_to_grayscale.argtypes = [vp, ll, ll, ll, C.c_int, vp]
         L.oracle_rgb_to_grayscale.restype = C.c_int
+        L.oracle_puploc_unpack.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
+        L.oracle_puploc_unpack.restype = C.c_int
+        L.oracle_puploc_free.argtypes = [vp]
+        L.oracle_puploc_free.restype = None
+        for name, typ in (("oracle_puploc_stages", C.c_uint32), ("oracle_puploc_trees", C.c_uint32), ("oracle_puploc_depth", C.c_uint32),
+                          ("oracle_puploc_scales", C.c_float), ("oracle_puploc_codes", C.POINTER(C.c_int8)),
+                          ("oracle_puploc_preds", C.POINTER(C.c_float))):
+            getattr(L, name).argtypes = [vp]
+            getattr(L, name).restype = typ
+        L.oracle_puploc_classify.argtypes = [vp, C.c_float, C.c_float, C.c_float, dbl, C.c_int, ll, ll, vp, ll, ll, C.c_int, vp]
+        L.oracle_puploc_classify.restype = C.c_int
+        L.oracle_puploc_run_detector.argtypes = [vp, vp, vp, ll, ll, ll, ll, dbl, C.c_int, vp, vp, vp]
+        L.oracle_puploc_run_detector.restype = C.c_int
+        L.oracle_get_landmark_point.argtypes = [vp, vp, vp, vp, ll, ll, ll, ll, ll, C.c_int, vp, vp, vp]
+        L.oracle_get_landmark_point.restype = C.c_int
         _lib = L
     return _lib
 
@@ -200,3 +215,86 @@ def rgb_to_grayscale(pix, kind=PIX_NRGBA):
         if rc != 0:
             raise ValueError("unknown pixel kind %r" % (kind,))
     return out
+
+
+class _PuplocDet(C.Structure):
+    """Puploc, core/puploc.go:14-19 (Go/amd64 layout: int, int, float32, int)"""
+    _fields_ = [("row", C.c_longlong), ("col", C.c_longlong), ("scale", C.c_float), ("perturbs", C.c_longlong)]
+
+
+class OraclePuploc:
+    """Restatement of ``type PuplocCascade`` (core/puploc.go:22-29) backed by the C oracle.
+
+    ``rnd`` everywhere = the 3*Perturbs values ``rand.Float32()`` would hand RunDetector (puploc.go:248-250), float32
+    in draw order; ``pool`` = the sync.Pool object's three 63-entry arrays (float32 [3, 63], modified in place) or
+    None for a brand-new one."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_puploc_free(self._h)
+            self._h = None
+
+    @classmethod
+    def unpack(cls, packet: bytes):  # UnpackCascade, puploc.go:38
+        h = C.c_void_p()
+        rc = lib().oracle_puploc_unpack(packet, len(packet), C.byref(h))
+        if rc == ERR_PANIC:
+            raise OraclePanic("UnpackCascade: packet too short (Go would panic)")
+        if rc != 0:
+            raise MemoryError("oracle_puploc_unpack failed")
+        return cls(h)
+
+    @property
+    def header(self):
+        L = lib()
+        return (int(L.oracle_puploc_stages(self._h)), float(L.oracle_puploc_scales(self._h)), int(L.oracle_puploc_trees(self._h)),
+                int(L.oracle_puploc_depth(self._h)))
+
+    def tables(self):
+        st, _, tr, d = self.header
+        L = lib()
+        nc, npred = st * tr * (4 * (1 << d) - 4), st * tr * (1 << d) * 2
+        return (np.ctypeslib.as_array(L.oracle_puploc_codes(self._h), shape=(nc,)).copy(),
+                np.ctypeslib.as_array(L.oracle_puploc_preds(self._h), shape=(npred,)).copy())
+
+    def classify(self, r, c, s, pixels, rows, cols, dim, angle=0.0, rotated=False, flip_v=False):
+        pixels = np.ascontiguousarray(pixels, dtype=np.uint8).ravel()
+        res = np.zeros(3, dtype=np.float32)
+        rc = lib().oracle_puploc_classify(self._h, r, c, s, angle, int(rotated), rows, cols, pixels.ctypes.data, pixels.size, dim,
+                                          int(flip_v), res.ctypes.data)
+        if rc == ERR_PANIC:
+            raise OraclePanic("puploc classifyRegion: index out of range")
+        return res
+
+    @staticmethod
+    def _pool(pool):
+        if pool is None:
+            return None
+        assert pool.dtype == np.float32 and pool.shape == (3, 63) and pool.flags.c_contiguous
+        return pool.ctypes.data
+
+    def run_detector(self, row, col, scale, perturbs, pixels, rows, cols, dim, angle, flip_v, rnd, pool=None):
+        """RunDetector, puploc.go:239 -> (row, col, scale)"""
+        pixels = np.ascontiguousarray(pixels, dtype=np.uint8).ravel()
+        rnd = np.ascontiguousarray(rnd, dtype=np.float32).ravel()
+        assert rnd.size >= 3 * max(min(perturbs, 63), 0)
+        pl, out = _PuplocDet(row, col, scale, perturbs), _PuplocDet()
+        rc = lib().oracle_puploc_run_detector(self._h, C.byref(pl), pixels.ctypes.data, pixels.size, rows, cols, dim, angle, int(flip_v),
+                                              rnd.ctypes.data, self._pool(pool), C.byref(out))
+        if rc == ERR_PANIC:
+            raise OraclePanic("RunDetector: index out of range")
+        return int(out.row), int(out.col), np.float32(out.scale)
+
+    def get_landmark_point(self, left_eye, right_eye, pixels, rows, cols, dim, perturb, flip_v, rnd, pool=None):
+        """GetLandmarkPoint, flploc.go:36; eyes are (row, col, scale) triples -> (row, col, scale)"""
+        pixels = np.ascontiguousarray(pixels, dtype=np.uint8).ravel()
+        rnd = np.ascontiguousarray(rnd, dtype=np.float32).ravel()
+        le, re, out = _PuplocDet(left_eye[0], left_eye[1], left_eye[2], 0), _PuplocDet(right_eye[0], right_eye[1], right_eye[2], 0), _PuplocDet()
+        rc = lib().oracle_get_landmark_point(self._h, C.byref(le), C.byref(re), pixels.ctypes.data, pixels.size, rows, cols, dim, perturb,
+                                             int(flip_v), rnd.ctypes.data, self._pool(pool), C.byref(out))
+        if rc == ERR_PANIC:
+            raise OraclePanic("GetLandmarkPoint: index out of range")
+        return int(out.row), int(out.col), np.float32(out.scale)

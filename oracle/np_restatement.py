@@ -174,3 +174,88 @@ def np_rgb_to_grayscale(pix, kind=0):
     v = np.float64(0.299) * f[..., 0] + np.float64(0.587) * f[..., 1]
     v = v + np.float64(0.114) * f[..., 2]
     return np.trunc(v / 256).astype(np.uint8).reshape(h * w)
+
+
+class NpPuploc:
+    """Independent restatement of PuplocCascade (core/puploc.go:22-277), vectorised over the perturbations.
+
+    Written from the Go text separately from oracle/pigo_oracle.c; every float32 step is a numpy float32 operation
+    (IEEE single, unfused), every integer step int64."""
+
+    Q_COS = np.array([256, 251, 236, 212, 181, 142, 97, 49, 0, -49, -97, -142, -181, -212, -236, -251, -256, -251, -236, -212, -181, -142,
+                      -97, -49, 0, 49, 97, 142, 181, 212, 236, 251, 256], dtype=np.float32)  # puploc.go:163
+    Q_SIN = np.array([0, 49, 97, 142, 181, 212, 236, 251, 256, 251, 236, 212, 181, 142, 97, 49, 0, -49, -97, -142, -181, -212, -236, -251,
+                      -256, -251, -236, -212, -181, -142, -97, -49, 0], dtype=np.float32)    # puploc.go:164
+
+    def __init__(self, packet: bytes):  # UnpackCascade, puploc.go:38-103
+        hdr = np.frombuffer(packet[:16], dtype="<u4")
+        self.stages, self.trees, self.depth = int(hdr[0]), int(hdr[2]), int(hdr[3])
+        self.scales = np.frombuffer(packet[4:8], dtype="<f4")[0]
+        D = 1 << self.depth
+        n = self.stages * self.trees
+        rec = np.frombuffer(packet, dtype=np.uint8, count=n * (12 * D - 4), offset=16).reshape(n, 12 * D - 4)
+        self.codes = rec[:, : 4 * D - 4].copy().view(np.int8).reshape(n, D - 1, 4)  # node k of a tree = bytes 4k..4k+3
+        self.preds = rec[:, 4 * D - 4:].copy().view("<f4").reshape(n, D, 2)
+
+    def classify(self, r, c, s, pixels, nrows, ncols, dim, flip_v=False, angle=None):
+        """classifyRegion (angle None) / classifyRotatedRegion over arrays of starting points -> (r, c, s) float32 arrays"""
+        pix = np.asarray(pixels, dtype=np.uint8).ravel()
+        r, c, s = (np.array(v, dtype=np.float32).copy() for v in (r, c, s))
+        D = 1 << self.depth
+        rot = angle is not None
+        if rot:
+            k = int(32.0 * angle)
+            qsin = (s * self.Q_SIN[k]).astype(np.float32).astype(np.int64)  # int(qsin): truncation
+            qcos = (s * self.Q_COS[k]).astype(np.float32).astype(np.int64)
+        lane = np.arange(r.size)
+        for i in range(self.stages):
+            dr = np.zeros(r.size, np.float32)
+            dc = np.zeros(r.size, np.float32)
+            ri, ci = r.astype(np.int64), c.astype(np.int64)                 # int(r), int(c): truncation toward zero
+            sr = np.where(s >= 0, np.floor(s.astype(np.float64) + 0.5), -np.floor(-s.astype(np.float64) + 0.5)).astype(np.int64)
+            for j in range(self.trees):
+                t = i * self.trees + j
+                idx = np.zeros(r.size, np.int64)
+                for _ in range(self.depth):
+                    cd = self.codes[t][idx].astype(np.int64)                # [P, 4]
+                    c1code, c2code = cd[:, 1], cd[:, 3]
+                    if flip_v:  # negation happens in int8 and wraps: -(-128) == -128
+                        c1code = (-self.codes[t][idx][:, 1]).astype(np.int8).astype(np.int64)
+                        c2code = (-self.codes[t][idx][:, 3]).astype(np.int8).astype(np.int64)
+                    if rot:
+                        r1 = np.minimum(nrows - 1, np.maximum(0, 65536 * ri + qcos * cd[:, 0] - qsin * c1code) >> 16)
+                        c1 = np.minimum(ncols - 1, np.maximum(0, 65536 * ci + qsin * cd[:, 0] + qcos * c1code) >> 16)
+                        r2 = np.minimum(nrows - 1, np.maximum(0, 65536 * ri + qcos * cd[:, 2] - qsin * c2code) >> 16)
+                        c2 = np.minimum(ncols - 1, np.maximum(0, 65536 * ci + qsin * cd[:, 2] + qcos * c2code) >> 16)
+                        bit = pix[r1 * dim + c1] <= pix[r2 * dim + c2]
+                    else:
+                        r1 = np.minimum(nrows - 1, np.maximum(0, (256 * ri + cd[:, 0] * sr) >> 8))
+                        r2 = np.minimum(nrows - 1, np.maximum(0, (256 * ri + cd[:, 2] * sr) >> 8))
+                        c1 = np.minimum(ncols - 1, np.maximum(0, (256 * ci + c1code * sr) >> 8))
+                        c2 = np.minimum(ncols - 1, np.maximum(0, (256 * ci + c2code * sr) >> 8))
+                        bit = pix[r1 * dim + c1] > pix[r2 * dim + c2]
+                    idx = 2 * idx + 1 + bit.astype(np.int64)
+                leaf = self.preds[t][idx - (D - 1)]                          # [P, 2]
+                dr = (dr + leaf[:, 0]).astype(np.float32)
+                dc = (dc + (-leaf[:, 1] if flip_v else leaf[:, 1])).astype(np.float32)
+            r = (r + (dr * s).astype(np.float32)).astype(np.float32)
+            c = (c + (dc * s).astype(np.float32)).astype(np.float32)
+            s = (s * self.scales).astype(np.float32)
+        del lane
+        return r, c, s
+
+    def run_detector(self, row, col, scale, perturbs, pixels, rows, cols, dim, angle, flip_v, rnd, pool=None):
+        """RunDetector, puploc.go:239-277 (pool: float32 [3, 63] in/out or None for a new sync.Pool object)"""
+        det = np.zeros((3, 63), np.float32) if pool is None else pool
+        u = np.asarray(rnd, dtype=np.float32).reshape(-1)[: 3 * perturbs].reshape(perturbs, 3)
+        f = np.float32
+        sc0 = f(scale)
+        rr = (f(row) + ((sc0 * f(0.15)) * (f(0.5) - u[:, 0])).astype(np.float32)).astype(np.float32)
+        cc = (f(col) + ((sc0 * f(0.15)) * (f(0.5) - u[:, 1])).astype(np.float32)).astype(np.float32)
+        ss = (sc0 * (f(0.925) + (f(0.15) * u[:, 2]).astype(np.float32)).astype(np.float32)).astype(np.float32)
+        a = None if not angle > 0.0 else min(angle, 1.0)
+        r, c, s = self.classify(rr, cc, ss, pixels, rows, cols, dim, flip_v, a)
+        det[0, :perturbs], det[1, :perturbs], det[2, :perturbs] = r, c, s
+        det.sort(axis=1)
+        mid = int(np.floor(perturbs / 2 + 0.5))
+        return int(det[0, mid]), int(det[1, mid]), np.float32(det[2, mid])

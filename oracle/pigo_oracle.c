@@ -739,3 +739,279 @@ int oracle_rgb_to_grayscale(const uint8_t *pix, gint width, gint height, gint st
     }
     return 0;
 }
+
+/* ======================================================================================================
+ * Pupil / facial-landmark localisation  (SURVEY.md section 8, rows f2 + f3: the step right after the scan)
+ *
+ *     PuplocCascade, UnpackCascade      /root/reference/core/puploc.go:22-103   (wire format, row f3)
+ *     (*PuplocCascade).classifyRegion   /root/reference/core/puploc.go:106-154
+ *     ...classifyRotatedRegion          /root/reference/core/puploc.go:157-217
+ *     (*PuplocCascade).RunDetector      /root/reference/core/puploc.go:239-277
+ *     (*PuplocCascade).GetLandmarkPoint /root/reference/core/flploc.go:36-57
+ *
+ * Two things in RunDetector are NOT a function of its arguments, so the restatement takes them as inputs:
+ *   - the perturbations come from the global math/rand source (puploc.go:248-250): `rnd` holds the 3*Perturbs
+ *     values rand.Float32() would return, in draw order (row, col, scale of perturbation 0, then 1, ...);
+ *   - the three 63-entry result arrays live in a sync.Pool object that is never cleared (puploc.go:228-237,
+ *     242-243) and are sorted WHOLE (puploc.go:267-269), so with Perturbs < 63 the entries [Perturbs, 63) are
+ *     whatever the previous user of that pool object left behind: `pool` (3*63 floats, in/out) is that object;
+ *     NULL means a brand-new one (all zeros, puploc.go:232-234).
+ * float32 arithmetic is evaluated operation by operation (Go/amd64 does not fuse; -ffp-contract=off here).
+ * PARITY UNPINNED like the rest of this file: the reference's tests only ask for "eyes found"
+ * (core/puploc_test.go:34-80) and "15 landmark points" (core/flploc_test.go).
+ * ====================================================================================================== */
+typedef struct {
+    int8_t *tree_codes; /* stages*trees*(4*2^depth - 4) bytes, no pad in front of a tree (puploc.go:76-79) */
+    float *tree_preds;  /* stages*trees*2^depth*2 */
+    float scales;
+    uint32_t stages, trees, tree_depth;
+    size_t n_codes, n_preds;
+} oracle_puploc;
+
+typedef struct { /* Puploc, puploc.go:14-19 */
+    gint row, col;
+    float scale;
+    gint perturbs;
+} oracle_puploc_det;
+
+void oracle_puploc_free(oracle_puploc *plc)
+{
+    if (!plc) return;
+    free(plc->tree_codes);
+    free(plc->tree_preds);
+    free(plc);
+}
+
+/* UnpackCascade, puploc.go:38-103 */
+int oracle_puploc_unpack(const uint8_t *packet, size_t len, oracle_puploc **out)
+{
+    *out = NULL;
+    if (len < 16) return ORACLE_ERR_PANIC; /* binary.LittleEndian.Uint32 on a short slice panics (:51-66) */
+    uint32_t stages = le32(packet + 0);    /* :51 */
+    uint32_t u32scales = le32(packet + 4); /* :55 */
+    float scales;
+    memcpy(&scales, &u32scales, 4);        /* :57 */
+    uint32_t trees = le32(packet + 8);     /* :61 */
+    uint32_t tree_depth = le32(packet + 12); /* :65 */
+    size_t pos = 16;
+    if (tree_depth > 20) return ORACLE_ERR_ALLOC;
+    gint depth = (gint)go_pow(2, (gint)tree_depth); /* :73 */
+    unsigned long long per_tree = (unsigned long long)(4 * depth - 4) + 8ull * (unsigned long long)depth;
+    unsigned long long need = 16ull + (unsigned long long)stages * trees * per_tree;
+    if ((unsigned long long)len < need) return ORACLE_ERR_PANIC; /* packet[pos : pos+4*depth-4] past the end (:75) */
+    oracle_puploc *plc = (oracle_puploc *)calloc(1, sizeof(*plc));
+    if (!plc) return ORACLE_ERR_ALLOC;
+    plc->stages = stages;
+    plc->scales = scales;
+    plc->trees = trees;
+    plc->tree_depth = tree_depth;
+    plc->n_codes = (size_t)stages * trees * (size_t)(4 * depth - 4);
+    plc->n_preds = (size_t)stages * trees * (size_t)depth * 2;
+    plc->tree_codes = (int8_t *)malloc(plc->n_codes ? plc->n_codes : 1);
+    plc->tree_preds = (float *)malloc((plc->n_preds ? plc->n_preds : 1) * sizeof(float));
+    if (!plc->tree_codes || !plc->tree_preds) {
+        oracle_puploc_free(plc);
+        return ORACLE_ERR_ALLOC;
+    }
+    size_t nc = 0, np = 0;
+    for (gint s = 0; s < (gint)stages; s++) {     /* :69 */
+        for (gint t = 0; t < (gint)trees; t++) {  /* :71 */
+            memcpy(plc->tree_codes + nc, packet + pos, (size_t)(4 * depth - 4)); /* :75-78 */
+            nc += (size_t)(4 * depth - 4);
+            pos += (size_t)(4 * depth - 4);       /* :80 */
+            for (gint i = 0; i < depth; i++)      /* :83 */
+                for (gint l = 0; l < 2; l++) {    /* :84 */
+                    uint32_t u = le32(packet + pos);
+                    float f;
+                    memcpy(&f, &u, 4);
+                    plc->tree_preds[np++] = f;    /* :85-88 */
+                    pos += 4;
+                }
+        }
+    }
+    *out = plc;
+    return ORACLE_OK;
+}
+
+uint32_t oracle_puploc_stages(const oracle_puploc *p) { return p->stages; }
+uint32_t oracle_puploc_trees(const oracle_puploc *p) { return p->trees; }
+uint32_t oracle_puploc_depth(const oracle_puploc *p) { return p->tree_depth; }
+float oracle_puploc_scales(const oracle_puploc *p) { return p->scales; }
+const int8_t *oracle_puploc_codes(const oracle_puploc *p) { return p->tree_codes; }
+const float *oracle_puploc_preds(const oracle_puploc *p) { return p->tree_preds; }
+
+/* int8 negation as Go does it: -plc.treeCodes[..] is evaluated in int8 and wraps (-(-128) == -128), puploc.go:123-124 */
+static gint neg_i8(int8_t v) { return (gint)(int8_t)(uint8_t)(0u - (uint8_t)v); }
+
+/* classifyRegion, puploc.go:106-154.  res = {r, c, s}; *panic set when a pixel index would be out of range. */
+static void puploc_classify_region(const oracle_puploc *plc, float r, float c, float s, gint tree_depth, gint nrows, gint ncols,
+                                   const uint8_t *pixels, gint npixels, gint dim, int flip_v, float *res, int *panic)
+{
+    gint c1, c2, root = 0;
+    for (gint i = 0; i < (gint)plc->stages; i++) {     /* :112 */
+        float dr = 0.0f, dc = 0.0f;                     /* :113 */
+        for (gint j = 0; j < (gint)plc->trees; j++) {  /* :115 */
+            gint idx = 0;
+            for (gint k = 0; k < (gint)plc->tree_depth; k++) { /* :117 */
+                const gint sr = (gint)llround((double)s);       /* int(math.Round(float64(s))) */
+                gint r1 = go_min(nrows - 1, go_max(0, (256 * (gint)r + (gint)plc->tree_codes[root + 4 * idx + 0] * sr) >> 8)); /* :118 */
+                gint r2 = go_min(nrows - 1, go_max(0, (256 * (gint)r + (gint)plc->tree_codes[root + 4 * idx + 2] * sr) >> 8)); /* :119 */
+                if (flip_v) { /* :123-125 */
+                    c1 = go_min(ncols - 1, go_max(0, (256 * (gint)c + neg_i8(plc->tree_codes[root + 4 * idx + 1]) * sr) >> 8));
+                    c2 = go_min(ncols - 1, go_max(0, (256 * (gint)c + neg_i8(plc->tree_codes[root + 4 * idx + 3]) * sr) >> 8));
+                } else {      /* :126-128 */
+                    c1 = go_min(ncols - 1, go_max(0, (256 * (gint)c + (gint)plc->tree_codes[root + 4 * idx + 1] * sr) >> 8));
+                    c2 = go_min(ncols - 1, go_max(0, (256 * (gint)c + (gint)plc->tree_codes[root + 4 * idx + 3] * sr) >> 8));
+                }
+                const gint i1 = r1 * dim + c1, i2 = r2 * dim + c2;
+                if (i1 < 0 || i1 >= npixels || i2 < 0 || i2 >= npixels) {
+                    *panic = 1;
+                    return;
+                }
+                idx = 2 * idx + 1 + (pixels[i1] > pixels[i2] ? 1 : 0); /* :130-136: bintest is p1 > p2 here */
+            }
+            const gint lut = 2 * ((gint)plc->trees * tree_depth * i + tree_depth * j + idx - (tree_depth - 1)); /* :138 */
+            dr += plc->tree_preds[lut + 0];                            /* :140 */
+            if (flip_v) dc += -plc->tree_preds[lut + 1];               /* :141-145 */
+            else dc += plc->tree_preds[lut + 1];
+            root += 4 * tree_depth - 4;                                /* :146 */
+        }
+        r += dr * s;          /* :149 */
+        c += dc * s;          /* :150 */
+        s *= plc->scales;     /* :151 */
+    }
+    res[0] = r;
+    res[1] = c;
+    res[2] = s;
+}
+
+/* classifyRotatedRegion, puploc.go:157-217 */
+static void puploc_classify_rotated_region(const oracle_puploc *plc, float r, float c, float s, double a, gint tree_depth, gint nrows,
+                                           gint ncols, const uint8_t *pixels, gint npixels, gint dim, int flip_v, float *res, int *panic)
+{
+    static const float q_cos_table[33] = {256, 251, 236, 212, 181, 142, 97, 49, 0, -49, -97, -142, -181, -212, -236, -251, -256,
+                                          -251, -236, -212, -181, -142, -97, -49, 0, 49, 97, 142, 181, 212, 236, 251, 256}; /* :163 */
+    static const float q_sin_table[33] = {0, 49, 97, 142, 181, 212, 236, 251, 256, 251, 236, 212, 181, 142, 97, 49, 0,
+                                          -49, -97, -142, -181, -212, -236, -251, -256, -251, -236, -212, -181, -142, -97, -49, 0}; /* :164 */
+    gint row1, col1, row2, col2, root = 0;
+    const gint ai = (gint)(32.0 * a);
+    if (ai < 0 || ai > 32) {
+        *panic = 1;
+        return;
+    }
+    const float qsin = s * q_sin_table[ai]; /* :166 */
+    const float qcos = s * q_cos_table[ai]; /* :167 */
+    for (gint i = 0; i < (gint)plc->stages; i++) {
+        float dr = 0.0f, dc = 0.0f;
+        for (gint j = 0; j < (gint)plc->trees; j++) {
+            gint idx = 0;
+            for (gint k = 0; k < (gint)plc->tree_depth; k++) {
+                row1 = (gint)plc->tree_codes[root + 4 * idx + 0]; /* :175 */
+                row2 = (gint)plc->tree_codes[root + 4 * idx + 2]; /* :176 */
+                if (flip_v) { /* :180-182 */
+                    col1 = neg_i8(plc->tree_codes[root + 4 * idx + 1]);
+                    col2 = neg_i8(plc->tree_codes[root + 4 * idx + 3]);
+                } else {      /* :183-185 */
+                    col1 = (gint)plc->tree_codes[root + 4 * idx + 1];
+                    col2 = (gint)plc->tree_codes[root + 4 * idx + 3];
+                }
+                const gint r1 = go_min(nrows - 1, go_max(0, 65536 * (gint)r + (gint)qcos * row1 - (gint)qsin * col1) >> 16); /* :188 */
+                const gint cc1 = go_min(ncols - 1, go_max(0, 65536 * (gint)c + (gint)qsin * row1 + (gint)qcos * col1) >> 16); /* :189 */
+                const gint r2 = go_min(nrows - 1, go_max(0, 65536 * (gint)r + (gint)qcos * row2 - (gint)qsin * col2) >> 16); /* :190 */
+                const gint cc2 = go_min(ncols - 1, go_max(0, 65536 * (gint)c + (gint)qsin * row2 + (gint)qcos * col2) >> 16); /* :191 */
+                const gint i1 = r1 * dim + cc1, i2 = r2 * dim + cc2;
+                if (i1 < 0 || i1 >= npixels || i2 < 0 || i2 >= npixels) {
+                    *panic = 1;
+                    return;
+                }
+                idx = 2 * idx + 1 + (pixels[i1] <= pixels[i2] ? 1 : 0); /* :193-199: bintest is px1 <= px2 here */
+            }
+            const gint lut = 2 * ((gint)plc->trees * tree_depth * i + tree_depth * j + idx - (tree_depth - 1)); /* :201 */
+            dr += plc->tree_preds[lut + 0];
+            if (flip_v) dc += -plc->tree_preds[lut + 1];
+            else dc += plc->tree_preds[lut + 1];
+            root += 4 * tree_depth - 4;
+        }
+        r += dr * s; /* :212 */
+        c += dc * s;
+        s *= plc->scales;
+    }
+    res[0] = r;
+    res[1] = c;
+    res[2] = s;
+}
+
+/* one perturbation, exported for the tests: which==0 upright, 1 rotated */
+int oracle_puploc_classify(const oracle_puploc *plc, float r, float c, float s, double a, int rotated, gint nrows, gint ncols,
+                           const uint8_t *pixels, gint npixels, gint dim, int flip_v, float *res)
+{
+    int panic = 0;
+    const gint td = (gint)go_pow(2, (gint)plc->tree_depth);
+    if (rotated) puploc_classify_rotated_region(plc, r, c, s, a, td, nrows, ncols, pixels, npixels, dim, flip_v, res, &panic);
+    else puploc_classify_region(plc, r, c, s, td, nrows, ncols, pixels, npixels, dim, flip_v, res, &panic);
+    return panic ? ORACLE_ERR_PANIC : ORACLE_OK;
+}
+
+static int f32_less(const void *a, const void *b) /* plocSort.Less: q[i] < q[j]; values are finite, so any sort gives one result */
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return x < y ? -1 : (y < x ? 1 : 0);
+}
+
+/* RunDetector, puploc.go:239-277.  rnd: 3*Perturbs uniform [0,1) float32 in draw order; pool: 3*63 floats in/out or NULL. */
+int oracle_puploc_run_detector(const oracle_puploc *plc, const oracle_puploc_det *pl, const uint8_t *pixels, gint npixels, gint rows,
+                               gint cols, gint dim, double angle, int flip_v, const float *rnd, float *pool, oracle_puploc_det *out)
+{
+    float fresh[3 * 63];
+    memset(fresh, 0, sizeof fresh);          /* plcPool.New: make([]float32, 63) x 3  (:231-235) */
+    float *det_rows = pool ? pool : fresh, *det_cols = det_rows + 63, *det_scale = det_rows + 126;
+    const gint tree_depth = (gint)go_pow(2, (gint)plc->tree_depth); /* :245 */
+    float res[3];
+    int panic = 0;
+    if (pl->perturbs > 63) return ORACLE_ERR_PANIC; /* det.rows[63] = ...: index out of range (:262) -- after 63 iterations of work */
+    for (gint i = 0; i < pl->perturbs; i++) {        /* :247 */
+        const float u0 = rnd[3 * i + 0], u1 = rnd[3 * i + 1], u2 = rnd[3 * i + 2];
+        float row = (float)pl->row + ((float)pl->scale * 0.15f) * (0.5f - u0); /* :248 */
+        float col = (float)pl->col + ((float)pl->scale * 0.15f) * (0.5f - u1); /* :249 */
+        float sc = (float)pl->scale * (0.925f + 0.15f * u2);                   /* :250 */
+        if (angle > 0.0) {            /* :252 */
+            if (angle > 1.0) angle = 1.0; /* :253-255 */
+            puploc_classify_rotated_region(plc, row, col, sc, angle, tree_depth, rows, cols, pixels, npixels, dim, flip_v, res, &panic);
+        } else {
+            puploc_classify_region(plc, row, col, sc, tree_depth, rows, cols, pixels, npixels, dim, flip_v, res, &panic);
+        }
+        if (panic) return ORACLE_ERR_PANIC;
+        det_rows[i] = res[0];  /* :262-264 */
+        det_cols[i] = res[1];
+        det_scale[i] = res[2];
+    }
+    qsort(det_rows, 63, sizeof(float), f32_less);  /* sort.Sort(plocSort(det.rows)): all 63 entries (:267-269) */
+    qsort(det_cols, 63, sizeof(float), f32_less);
+    qsort(det_scale, 63, sizeof(float), f32_less);
+    const gint mid = (gint)llround((double)pl->perturbs / 2); /* int(math.Round(float64(pl.Perturbs)/2)) (:273) */
+    if (mid < 0 || mid >= 63) return ORACLE_ERR_PANIC;
+    out->row = (gint)det_rows[mid];   /* :273 */
+    out->col = (gint)det_cols[mid];   /* :274 */
+    out->scale = det_scale[mid];      /* :275 */
+    out->perturbs = 0;                /* the returned &Puploc{} leaves Perturbs at its zero value */
+    return ORACLE_OK;
+}
+
+/* GetLandmarkPoint, flploc.go:36-57 */
+int oracle_get_landmark_point(const oracle_puploc *plc, const oracle_puploc_det *left_eye, const oracle_puploc_det *right_eye,
+                              const uint8_t *pixels, gint npixels, gint rows, gint cols, gint dim, gint perturb, int flip_v,
+                              const float *rnd, float *pool, oracle_puploc_det *out)
+{
+    const gint dx = (left_eye->row - right_eye->row) * (left_eye->row - right_eye->row); /* :37 */
+    const gint dy = (left_eye->col - right_eye->col) * (left_eye->col - right_eye->col); /* :38 */
+    const double dist = sqrt((double)(dx + dy));                                         /* :39 */
+    const double row = (double)(left_eye->row + right_eye->row) / 2.0 + 0.25 * dist;     /* :41 */
+    const double col = (double)(left_eye->col + right_eye->col) / 2.0 + 0.15 * dist;     /* :42 */
+    const double scale = 3.0 * dist;                                                     /* :43 */
+    oracle_puploc_det flploc;
+    flploc.row = (gint)row;          /* :48 */
+    flploc.col = (gint)col;          /* :49 */
+    flploc.scale = (float)scale;     /* :50 */
+    flploc.perturbs = perturb;       /* :51 */
+    return oracle_puploc_run_detector(plc, &flploc, pixels, npixels, rows, cols, dim, 0.0, flip_v, rnd, pool, out); /* :53-56 */
+}

@@ -51,6 +51,8 @@ ABI_SYMBOLS = [
     "pigo_plan_set_variant", "pigo_plan_run", "pigo_plan_cluster", "pigo_plan_status", "pigo_plan_run_sync", "pigo_plan_set_profiling",
     "pigo_plan_last_timings", "pigo_plan_last_queue_count", "pigo_plan_debug_stats", "pigo_plan_debug_trace",
     "pigo_rgb_to_grayscale", "pigo_gray_batch",
+    "pigo_puploc_create", "pigo_puploc_info", "pigo_puploc_destroy", "pigo_puploc_run_detector", "pigo_get_landmark_point",
+    "pigo_puploc_run_batch", "pigo_puploc_status",
 ]
 
 _lib = None
@@ -98,6 +100,14 @@ def load_library():
     L.pigo_plan_debug_trace.argtypes = [vp, C.POINTER(C.c_uint64), i32]
     L.pigo_rgb_to_grayscale.argtypes = [i32, vp, sz, i32, i32, i32, i32, vp, sz]
     L.pigo_gray_batch.argtypes = [i32, vp, sz, i32, i32, i32, i32, i32, vp, sz, i32, vp]
+    L.pigo_puploc_create.argtypes = [C.c_char_p, sz, i32, C.POINTER(vp)]
+    L.pigo_puploc_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.pigo_puploc_destroy.argtypes = [vp]
+    L.pigo_puploc_destroy.restype = None
+    L.pigo_puploc_run_detector.argtypes = [vp, vp, vp, sz, i32, i32, i32, dbl, i32, vp, vp, vp]
+    L.pigo_get_landmark_point.argtypes = [vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.pigo_puploc_run_batch.argtypes = [vp, vp, sz, i32, i32, i32, i32, dbl, vp, vp, vp, i32, vp, vp]
+    L.pigo_puploc_status.argtypes = [vp]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("pigo_device_count", "pigo_plan_last_timings"):
@@ -260,3 +270,115 @@ def RgbToGrayscale(src: np.ndarray, kind: int = PIX_NRGBA, device: int = 0) -> n
     check(load_library().pigo_rgb_to_grayscale(int(device), src.ctypes.data, npix, w, h, stride, int(kind), out.ctypes.data, out.size),
           "RgbToGrayscale")
     return out
+
+
+# ---- PuplocCascade: pupil / facial-landmark localisation (core/puploc.go, core/flploc.go) ---------------------------------
+
+#: Puploc wire record of the C ABI (pigo_puploc) and the batch request record (pigo_puploc_req)
+PUPLOC_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("scale", "<f4"), ("perturbs", "<i4")])
+PUPLOC_REQ_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("scale", "<f4"), ("perturbs", "<i4"), ("frame", "<i4"), ("flip_v", "<i4")])
+POOL_SIZE = 63  # entries of each of the three sync.Pool arrays, puploc.go:231-235
+
+
+@dataclass
+class Puploc:
+    """type Puploc, core/puploc.go:14-19"""
+    Row: int = 0
+    Col: int = 0
+    Scale: float = 0.0
+    Perturbs: int = 0
+
+
+def new_pool() -> np.ndarray:
+    """A brand-new sync.Pool object of RunDetector: rows | cols | scale, 63 float32 zeros each (puploc.go:228-237)."""
+    return np.zeros((3, POOL_SIZE), dtype=np.float32)
+
+
+def draw_perturbations(perturbs: int, rng=None) -> np.ndarray:
+    """What RunDetector takes from rand.Float32(): 3 values per perturbation in draw order (puploc.go:248-250)."""
+    rng = np.random.default_rng() if rng is None else rng
+    return rng.random(3 * max(int(perturbs), 0), dtype=np.float32)
+
+
+class PuplocCascade:
+    """type PuplocCascade (core/puploc.go:22-29) with device-resident tables.  NewPuplocCascade() == PuplocCascade()."""
+
+    def __init__(self, _handle=None, device=0):
+        self._h = _handle
+        self.device = device
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.pigo_puploc_destroy(h)
+
+    def _need(self):
+        if not self._h:
+            raise PigoError("PuplocCascade is not unpacked (call UnpackCascade first)")
+        return self._h
+
+    # UnpackCascade, core/puploc.go:38-103: returns a NEW cascade
+    def UnpackCascade(self, packet: bytes, device: int = None):
+        dev = self.device if device is None else device
+        h = C.c_void_p()
+        check(load_library().pigo_puploc_create(bytes(packet), len(packet), dev, C.byref(h)), "UnpackCascade")
+        return PuplocCascade(h, dev)
+
+    # UnpackFlp, core/flploc.go:27-33
+    def UnpackFlp(self, cf: str):
+        with open(cf, "rb") as fh:
+            return self.UnpackCascade(fh.read())
+
+    # ReadCascadeDir, core/flploc.go:60-81: file name -> [cascade]
+    def ReadCascadeDir(self, path: str):
+        names = sorted(os.listdir(path))
+        if not names:
+            raise PigoError("the provided directory is empty")
+        return {n: [self.UnpackFlp(os.path.join(os.path.abspath(path), n))] for n in names}
+
+    @property
+    def header(self):
+        """(stages, scales, trees, treeDepth)"""
+        st, tr, d, sc = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_float()
+        check(load_library().pigo_puploc_info(self._need(), C.byref(st), C.byref(sc), C.byref(tr), C.byref(d)))
+        return st.value, sc.value, tr.value, d.value
+
+    @staticmethod
+    def _args(img: ImageParams, perturbs, rnd, pool):
+        pix = np.ascontiguousarray(img.Pixels, dtype=np.uint8).ravel()
+        rnd = draw_perturbations(perturbs) if rnd is None else np.ascontiguousarray(rnd, dtype=np.float32).ravel()
+        if rnd.size < 3 * min(max(int(perturbs), 0), POOL_SIZE):
+            raise ValueError("rnd needs 3 values per perturbation")
+        if pool is not None and not (pool.dtype == np.float32 and pool.shape == (3, POOL_SIZE) and pool.flags.c_contiguous):
+            raise ValueError("pool must be a contiguous float32 [3, 63] array (see new_pool())")
+        return pix, rnd, (pool.ctypes.data if pool is not None else None)
+
+    # RunDetector, core/puploc.go:239-277
+    def RunDetector(self, pl: Puploc, img: ImageParams, angle: float, flipV: bool, rnd=None, pool=None) -> Puploc:
+        """``rnd``: the 3*Perturbs values rand.Float32() would return (None: drawn here, like the reference's global
+        source); ``pool``: the sync.Pool object, float32 [3, 63] read and written (None: a brand-new one)."""
+        pix, rnd, pp = self._args(img, pl.Perturbs, rnd, pool)
+        req = np.zeros(1, dtype=PUPLOC_DTYPE)
+        req[0] = (int(pl.Row), int(pl.Col), float(pl.Scale), int(pl.Perturbs))
+        out = np.zeros(1, dtype=PUPLOC_DTYPE)
+        check(load_library().pigo_puploc_run_detector(self._need(), req.ctypes.data, pix.ctypes.data, pix.size, int(img.Rows), int(img.Cols),
+                                                      int(img.Dim), float(angle), int(bool(flipV)), rnd.ctypes.data, pp, out.ctypes.data),
+              "RunDetector")
+        return Puploc(int(out[0]["row"]), int(out[0]["col"]), float(out[0]["scale"]), 0)
+
+    # GetLandmarkPoint, core/flploc.go:36-57
+    def GetLandmarkPoint(self, leftEye: Puploc, rightEye: Puploc, img: ImageParams, perturb: int, flipV: bool, rnd=None, pool=None) -> Puploc:
+        pix, rnd, pp = self._args(img, perturb, rnd, pool)
+        eyes = np.zeros(2, dtype=PUPLOC_DTYPE)
+        eyes[0] = (int(leftEye.Row), int(leftEye.Col), float(leftEye.Scale), 0)
+        eyes[1] = (int(rightEye.Row), int(rightEye.Col), float(rightEye.Scale), 0)
+        out = np.zeros(1, dtype=PUPLOC_DTYPE)
+        check(load_library().pigo_get_landmark_point(self._need(), eyes[0:1].ctypes.data, eyes[1:2].ctypes.data, pix.ctypes.data, pix.size,
+                                                     int(img.Rows), int(img.Cols), int(img.Dim), int(perturb), int(bool(flipV)),
+                                                     rnd.ctypes.data, pp, out.ctypes.data), "GetLandmarkPoint")
+        return Puploc(int(out[0]["row"]), int(out[0]["col"]), float(out[0]["scale"]), 0)
+
+
+def NewPuplocCascade(device: int = 0) -> PuplocCascade:
+    """core/puploc.go:32-34"""
+    return PuplocCascade(device=device)

@@ -1426,3 +1426,212 @@ extern "C" pigo_status pigo_rgb_to_grayscale(int device, const uint8_t *pix, siz
     HIP_TRY(hipMemcpy(gray, d_dst.p, npx, hipMemcpyDeviceToHost));  // synchronises with the null stream
     return PIGO_OK;
 }
+
+// ---- PuplocCascade: UnpackCascade / RunDetector / GetLandmarkPoint (core/puploc.go, core/flploc.go) --------------------
+
+struct pigo_puploc_cascade {
+    int device = 0;
+    uint32_t stages = 0, trees = 0, depth = 0;
+    float scales = 0.0f;
+    DevBuf<int8_t> d_codes;
+    DevBuf<float> d_preds;
+    DevBuf<int32_t> d_flags;
+    std::mutex mu;  // serialises the single-request entry points (they share the scratch below)
+    DevBuf<uint8_t> d_frame;
+    DevBuf<PuplocReq> d_req;
+    DevBuf<float> d_rnd, d_pool;
+    DevBuf<PuplocOut> d_out;
+};
+
+static_assert(sizeof(PuplocReq) == sizeof(pigo_puploc_req) && sizeof(PuplocOut) == sizeof(pigo_puploc), "wire records");
+
+extern "C" pigo_status pigo_puploc_create(const uint8_t *packet, size_t len, int device, pigo_puploc_cascade **out)
+{
+    if (!out) return fail(PIGO_ERR_PARAM, "out is NULL");
+    *out = nullptr;
+    if (!packet || len < 16) return fail(PIGO_ERR_PACKET, "UnpackCascade: packet shorter than its 16-byte header (%zu bytes)", len);
+    const uint32_t stages = le32(packet), trees = le32(packet + 8), depth = le32(packet + 12);  // puploc.go:51-66
+    float scales;
+    const uint32_t u = le32(packet + 4);
+    memcpy(&scales, &u, 4);
+    if (depth < 1 || depth > 14) return fail(PIGO_ERR_PARAM, "UnpackCascade: tree depth %u outside [1, 14]", depth);
+    if (stages > 4096 || trees > 4096) return fail(PIGO_ERR_PARAM, "UnpackCascade: %u stages x %u trees is not a plausible cascade", stages, trees);
+    const size_t TD = (size_t)1 << depth, ncode = 4 * TD - 4, npred = 2 * TD, ntree = (size_t)stages * trees;
+    if (len < 16 + ntree * (ncode + 4 * npred))  // packet[pos : pos+4*depth-4] past the end: the reference panics (puploc.go:75)
+        return fail(PIGO_ERR_PACKET, "UnpackCascade: %zu bytes, header needs %zu", len, 16 + ntree * (ncode + 4 * npred));
+    std::vector<int8_t> codes(ntree * ncode);
+    std::vector<float> preds(ntree * npred);
+    size_t pos = 16;
+    for (size_t t = 0; t < ntree; ++t) {  // puploc.go:69-93
+        memcpy(codes.data() + t * ncode, packet + pos, ncode);
+        pos += ncode;
+        memcpy(preds.data() + t * npred, packet + pos, 4 * npred);  // little-endian float32, like this host
+        pos += 4 * npred;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(PIGO_ERR_HIP, "no usable HIP device %d (%d visible): libpigo_hip has no CPU fallback", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<pigo_puploc_cascade> c(new pigo_puploc_cascade);
+    c->device = device;
+    c->stages = stages;
+    c->trees = trees;
+    c->depth = depth;
+    c->scales = scales;
+    HIP_TRY(c->d_codes.alloc(codes.size() + 8));  // + slack: the child prefetch of a leaf-level node is never issued, but keep loads in bounds
+    HIP_TRY(c->d_preds.alloc(preds.size()));
+    HIP_TRY(c->d_flags.alloc(4));
+    HIP_TRY(hipMemset(c->d_flags.p, 0, 16));
+    if (!codes.empty()) HIP_TRY(hipMemcpy(c->d_codes.p, codes.data(), codes.size(), hipMemcpyHostToDevice));
+    if (!preds.empty()) HIP_TRY(hipMemcpy(c->d_preds.p, preds.data(), preds.size() * 4, hipMemcpyHostToDevice));
+    *out = c.release();
+    return PIGO_OK;
+}
+
+extern "C" pigo_status pigo_puploc_info(const pigo_puploc_cascade *c, uint32_t *stages, float *scales, uint32_t *trees, uint32_t *tree_depth)
+{
+    if (!c) return fail(PIGO_ERR_PARAM, "cascade is NULL");
+    if (stages) *stages = c->stages;
+    if (scales) *scales = c->scales;
+    if (trees) *trees = c->trees;
+    if (tree_depth) *tree_depth = c->depth;
+    return PIGO_OK;
+}
+
+extern "C" void pigo_puploc_destroy(pigo_puploc_cascade *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    delete c;
+}
+
+namespace {
+
+pigo_status puploc_launch(pigo_puploc_cascade *c, const uint8_t *d_frames, size_t frame_stride, int nframes, int rows, int cols, int dim,
+                          double angle, const PuplocReq *d_reqs, const float *d_rnd, float *d_pool, int n, PuplocOut *d_out, hipStream_t st)
+{
+    if (rows < 1 || cols < 1) return fail(PIGO_ERR_PANIC, "RunDetector: rows=%d cols=%d (min(nrows-1, ...) indexes before the image)", rows, cols);
+    if (dim < cols || rows >= 65536 || dim >= 65536) return fail(PIGO_ERR_PARAM, "RunDetector: need cols <= dim < 65536 and rows < 65536");
+    if (nframes < 1 || (nframes > 1 && frame_stride < (size_t)(rows - 1) * dim + cols)) return fail(PIGO_ERR_PARAM, "RunDetector: bad frame batch");
+    if (n == 0) return PIGO_OK;
+    if (c->stages == 0 || c->trees == 0) return fail(PIGO_ERR_PARAM, "RunDetector: empty cascade");
+    PuplocArgs a{};
+    a.codes = c->d_codes.p;
+    a.preds = c->d_preds.p;
+    a.scales = c->scales;
+    a.stages = (int)c->stages;
+    a.trees = (int)c->trees;
+    a.depth = (int)c->depth;
+    a.frames = d_frames;
+    a.frame_stride = frame_stride;
+    a.nrows = rows;
+    a.ncols = cols;
+    a.dim = dim;
+    a.nframes = nframes;
+    a.reqs = d_reqs;
+    a.rnd = d_rnd;
+    a.pool = d_pool;
+    a.out = d_out;
+    a.flags = c->d_flags.p;
+    if (angle > 0.0) {  // puploc.go:252-256
+        if (angle > 1.0) angle = 1.0;
+        const int k = (int)(32.0 * angle);
+        a.qcos = (float)kQCos[k];  // the same 33-entry tables as the face cascade (puploc.go:163-164 == pigo.go:156-157)
+        a.qsin = (float)kQSin[k];
+        hipLaunchKernelGGL((k_puploc<true>), dim3((unsigned)n), dim3(kPupThreads), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((k_puploc<false>), dim3((unsigned)n), dim3(kPupThreads), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return PIGO_OK;
+}
+
+}  // namespace
+
+extern "C" pigo_status pigo_puploc_run_batch(pigo_puploc_cascade *c, const uint8_t *d_frames, size_t frame_stride, int nframes, int rows,
+                                             int cols, int dim, double angle, const pigo_puploc_req *d_reqs, const float *d_rnd,
+                                             float *d_pool, int n, pigo_puploc *d_out, void *stream)
+{
+    if (!c) return fail(PIGO_ERR_PARAM, "cascade is NULL");
+    if (n < 0) return fail(PIGO_ERR_PARAM, "n < 0");
+    if (n > 0 && (!d_frames || !d_reqs || !d_rnd || !d_out)) return fail(PIGO_ERR_PARAM, "NULL device pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    return puploc_launch(c, d_frames, frame_stride, nframes, rows, cols, dim, angle, reinterpret_cast<const PuplocReq *>(d_reqs), d_rnd, d_pool, n,
+                         reinterpret_cast<PuplocOut *>(d_out), (hipStream_t)stream);
+}
+
+extern "C" pigo_status pigo_puploc_status(pigo_puploc_cascade *c)
+{
+    if (!c) return fail(PIGO_ERR_PARAM, "cascade is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    int32_t f = 0;
+    HIP_TRY(hipMemcpy(&f, c->d_flags.p, 4, hipMemcpyDeviceToHost));
+    if (f) {
+        HIP_TRY(hipMemset(c->d_flags.p, 0, 4));
+        return fail(PIGO_ERR_PANIC, "RunDetector: a request had Perturbs outside [0, 63] or a frame index out of range (the reference panics)");
+    }
+    return PIGO_OK;
+}
+
+extern "C" pigo_status pigo_puploc_run_detector(pigo_puploc_cascade *c, const pigo_puploc *pl, const uint8_t *pixels, size_t npixels, int rows,
+                                                int cols, int dim, double angle, int flip_v, const float *rnd, float *pool, pigo_puploc *out)
+{
+    if (!c || !pl || !out) return fail(PIGO_ERR_PARAM, "NULL argument");
+    if (pl->perturbs < 0 || pl->perturbs > kPupPool)  // det.rows[63] = res[0] / det.rows[int(math.Round(-n/2))]: index out of range
+        return fail(PIGO_ERR_PANIC, "RunDetector: Perturbs=%d outside [0, 63]", pl->perturbs);
+    if (rows < 1 || cols < 1) return fail(PIGO_ERR_PANIC, "RunDetector: rows=%d cols=%d", rows, cols);
+    if (dim < cols) return fail(PIGO_ERR_PARAM, "RunDetector: dim=%d < cols=%d", dim, cols);
+    const size_t fbytes = (size_t)(rows - 1) * (size_t)dim + (size_t)cols;
+    if (!pixels || npixels < fbytes) return fail(PIGO_ERR_PANIC, "RunDetector: len(pixels)=%zu < %zu", pixels ? npixels : (size_t)0, fbytes);
+    if (pl->perturbs > 0 && !rnd) return fail(PIGO_ERR_PARAM, "RunDetector: rnd is NULL");
+    if (!(std::fabs((double)pl->scale) < 1e6) || std::abs((long long)pl->row) > (1 << 24) || std::abs((long long)pl->col) > (1 << 24))
+        return fail(PIGO_ERR_PARAM, "RunDetector: Puploc{%d, %d, %g} outside the supported range", pl->row, pl->col, (double)pl->scale);
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->d_frame.n < fbytes) HIP_TRY(c->d_frame.alloc(fbytes));
+    if (!c->d_req.p) {
+        HIP_TRY(c->d_req.alloc(1));
+        HIP_TRY(c->d_rnd.alloc(3 * kPupPool));
+        HIP_TRY(c->d_pool.alloc(3 * kPupPool));
+        HIP_TRY(c->d_out.alloc(1));
+    }
+    const PuplocReq rq{pl->row, pl->col, pl->scale, pl->perturbs, 0, flip_v ? 1 : 0};
+    float hr[3 * kPupPool] = {0};
+    // the kernel indexes rnd as [63][3]; Go draws row, col, scale for perturbation 0, then 1, ... -- the same layout
+    if (pl->perturbs) memcpy(hr, rnd, sizeof(float) * 3 * (size_t)pl->perturbs);
+    HIP_TRY(hipMemcpy(c->d_frame.p, pixels, fbytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_req.p, &rq, sizeof rq, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_rnd.p, hr, sizeof hr, hipMemcpyHostToDevice));
+    if (pool) HIP_TRY(hipMemcpy(c->d_pool.p, pool, sizeof(float) * 3 * kPupPool, hipMemcpyHostToDevice));
+    pigo_status st = puploc_launch(c, c->d_frame.p, fbytes, 1, rows, cols, dim, angle, c->d_req.p, c->d_rnd.p, pool ? c->d_pool.p : nullptr, 1,
+                                   c->d_out.p, nullptr);
+    if (st != PIGO_OK) return st;
+    PuplocOut o{};
+    HIP_TRY(hipMemcpy(&o, c->d_out.p, sizeof o, hipMemcpyDeviceToHost));
+    if (pool) HIP_TRY(hipMemcpy(pool, c->d_pool.p, sizeof(float) * 3 * kPupPool, hipMemcpyDeviceToHost));
+    out->row = o.row;
+    out->col = o.col;
+    out->scale = o.scale;
+    out->perturbs = 0;  // &Puploc{Row, Col, Scale}: Perturbs stays zero (puploc.go:272-276)
+    return PIGO_OK;
+}
+
+extern "C" pigo_status pigo_get_landmark_point(pigo_puploc_cascade *c, const pigo_puploc *left_eye, const pigo_puploc *right_eye,
+                                               const uint8_t *pixels, size_t npixels, int rows, int cols, int dim, int perturb, int flip_v,
+                                               const float *rnd, float *pool, pigo_puploc *out)
+{
+    if (!left_eye || !right_eye) return fail(PIGO_ERR_PARAM, "NULL eye");
+    // flploc.go:37-51, in Go's int (64-bit) and float64
+    const long long dx = ((long long)left_eye->row - right_eye->row) * ((long long)left_eye->row - right_eye->row);
+    const long long dy = ((long long)left_eye->col - right_eye->col) * ((long long)left_eye->col - right_eye->col);
+    const double dist = std::sqrt((double)(dx + dy));
+    const double row = (double)((long long)left_eye->row + right_eye->row) / 2.0 + 0.25 * dist;
+    const double col = (double)((long long)left_eye->col + right_eye->col) / 2.0 + 0.15 * dist;
+    const double scale = 3.0 * dist;
+    pigo_puploc flploc;
+    flploc.row = (int32_t)(long long)row;
+    flploc.col = (int32_t)(long long)col;
+    flploc.scale = (float)scale;
+    flploc.perturbs = perturb;
+    return pigo_puploc_run_detector(c, &flploc, pixels, npixels, rows, cols, dim, 0.0, flip_v, rnd, pool, out);  // flploc.go:53-56
+}

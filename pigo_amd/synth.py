@@ -98,3 +98,16 @@ def syn_rgba(rows: int, cols: int, seed: int = 1234, frame_index: int = 0, opaqu
     k = rows if opaque_rows is None else opaque_rows
     a[:k, :, 3] = 255
     return a
+
+
+def syn_uniform32(n: int, seed: int = 1234, index: int = 0) -> np.ndarray:
+    """n seeded float32 values in [0, 1) (24 random bits each) -- stands in for math/rand's rand.Float32() stream that
+    RunDetector draws its perturbations from (core/puploc.go:248-250)."""
+    words = _splitmix64_block(_frame_seed(seed ^ 0xF10A7, index), n)
+    return ((words >> np.uint64(40)).astype(np.float32) / np.float32(1 << 24)).astype(np.float32)
+
+
+def cascade_bytes(name: str) -> bytes:
+    """A cascade file shipped as data: "facefinder", "puploc", "lps/lp42", ..."""
+    with open(os.path.join(_DATA, *name.split("/")), "rb") as fh:
+        return fh.read()

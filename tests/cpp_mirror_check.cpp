@@ -26,8 +26,23 @@ int main(int argc, char **argv)
         const std::vector<uint8_t> g177 = pigo::RgbToGrayscale(pigo::Image{&pix, 40, 10, 10, PIGO_PIX_RGBA});
         bool gray_ok = g177.size() == 100;
         for (uint8_t v : g177) gray_ok = gray_ok && v == 177;
-        std::printf(" gray177=%d\n", gray_ok ? 1 : 0);
-        return cl.empty() || !gray_ok ? 1 : 0;
+        std::printf(" gray177=%d", gray_ok ? 1 : 0);
+        bool eye_ok = true;
+        if (argc > 3) {  // core/puploc_test.go:34-80 on the cluster found above, with a fixed rand.Float32() stream
+            std::ifstream pf(argv[3], std::ios::binary);
+            std::vector<uint8_t> ppk((std::istreambuf_iterator<char>(pf)), std::istreambuf_iterator<char>());
+            pigo::PuplocCascade plc = pigo::NewPuplocCascade().UnpackCascade(ppk);
+            pigo::DetectorState st;
+            uint32_t lcg = 12345u;
+            st.Float32 = [&lcg]() { lcg = lcg * 1664525u + 1013904223u; return (float)(lcg >> 8) / 16777216.0f; };
+            const pigo::Detection &d = cl[0];
+            pigo::Puploc req{d.Row - (int)(0.075f * (float)d.Scale), d.Col - (int)(0.175f * (float)d.Scale), (float)d.Scale * 0.25f, 63};
+            const pigo::Puploc eye = plc.RunDetector(req, cp.ImageParams, 0.0, false, st);
+            eye_ok = eye.Row > d.Row - d.Scale / 2 && eye.Row < d.Row && eye.Col > d.Col - d.Scale / 2 && eye.Col < d.Col;
+            std::printf(" eye=(%d,%d,%.3f) eye_ok=%d", eye.Row, eye.Col, eye.Scale, eye_ok ? 1 : 0);
+        }
+        std::printf("\n");
+        return cl.empty() || !gray_ok || !eye_ok ? 1 : 0;
     } catch (const pigo::Panic &e) {
         std::printf("panic: %s\n", e.what());
         return 3;

@@ -8,6 +8,8 @@ Run in the BUILD container only (needs /root/reference, which is absent on the G
 Writes
   pigo_amd/data/facefinder               the reference's face cascade (model DATA, not source;
                                          /root/reference/cascade/facefinder, 239,632 B)
+  pigo_amd/data/puploc, lps/lp*          the pupil / facial-landmark cascades (model DATA; cascade/puploc 1,228,416 B,
+                                         the nine cascade/lps/lp* files 736,816 B each) for scope rows f2/f3
   pigo_amd/data/sample_gray_320x400.bin  testdata/sample.jpg decoded with Pillow and converted with
                                          the reference's gray formula (core/grayscale.go:8-23):
                                          uint8((0.299*r16 + 0.587*g16 + 0.114*b16) / 256) in float64
@@ -33,6 +35,7 @@ EXPECT = {
     "cascade/facefinder": "d8014993e7298c7b1865d1f8b855d6dbf4ec5c808bf879e2091ab6837abf90cd",
     "testdata/sample.jpg": "09ee4f7085e1eee6f48d3a2b11791c4c008e2dc0c6b2b2462067104e3030915e",
 }
+EXTRA_CASCADES = ["cascade/puploc"] + ["cascade/lps/" + n for n in ("lp312", "lp38", "lp42", "lp44", "lp46", "lp81", "lp82", "lp84", "lp93")]
 
 
 def sha(path):
@@ -47,6 +50,12 @@ def main():
     os.makedirs(DATA, exist_ok=True)
     shutil.copyfile(os.path.join(REF, "cascade/facefinder"), os.path.join(DATA, "facefinder"))
     os.chmod(os.path.join(DATA, "facefinder"), 0o644)
+    for rel in EXTRA_CASCADES:
+        dst = os.path.join(DATA, rel[len("cascade/"):])
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        shutil.copyfile(os.path.join(REF, rel), dst)
+        os.chmod(dst, 0o644)
+        print(os.path.basename(rel), sha(dst))
 
     rgb = np.asarray(Image.open(os.path.join(REF, "testdata/sample.jpg")).convert("RGB"), dtype=np.float64)
     r16, g16, b16 = rgb[..., 0] * 257.0, rgb[..., 1] * 257.0, rgb[..., 2] * 257.0

@@ -303,6 +303,6 @@ def test_cpp_mirror_runs_on_gpu(tmp_path):
     exe = str(tmp_path / "cpp_mirror_check")
     subprocess.check_call([gxx, "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp_mirror_check.cpp"),
                            "-o", exe, "-L" + csrc, "-lpigo_hip", "-Wl,-rpath," + csrc])
-    r = subprocess.run([exe, os.path.join(root, "pigo_amd", "data", "facefinder"), os.path.join(root, "pigo_amd", "data", "sample_gray_320x400.bin")],
-                       capture_output=True, text=True)
-    assert r.returncode == 0 and "dets=4 clusters=1 (206,154,261," in r.stdout and "gray177=1" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    r = subprocess.run([exe, os.path.join(root, "pigo_amd", "data", "facefinder"), os.path.join(root, "pigo_amd", "data", "sample_gray_320x400.bin"),
+                        os.path.join(root, "pigo_amd", "data", "puploc")], capture_output=True, text=True)
+    assert r.returncode == 0 and "dets=4 clusters=1 (206,154,261," in r.stdout and "gray177=1" in r.stdout and "eye_ok=1" in r.stdout, (r.returncode, r.stdout, r.stderr)
