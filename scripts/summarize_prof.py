@@ -24,7 +24,7 @@ def main():
         cur = sqlite3.connect(db).cursor()
         print("\n# rocprofv3 --pmc pass %s (separate run; mean per dispatch, summed over the chip)" % db.split("/")[-2])
         q = ("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
-             "where kernel_name like '%k_scan%' or kernel_name like '%k_tail%' or kernel_name like '%k_cluster%' group by kernel_name, counter_name")
+             "where kernel_name like '%k_scan%' or kernel_name like '%k_tail%' or kernel_name like '%k_cluster%' or kernel_name like '%k_rgb_to_gray%' or kernel_name like '%k_puploc%' group by kernel_name, counter_name")
         for k, c, n, avg in cur.execute(q):
             print("%-40s %-30s n=%3d mean=%.6g" % (short(k)[:40], c, n, avg))
 
