@@ -62,6 +62,30 @@ def library_path():
     return _build.LIB
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch's ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64; if
+    libpigo_hip.so pulled in /opt/rocm's copy first, a later `import torch` would bring a second HSA runtime into the
+    process and find no GPUs (and streams could not be shared).  So when torch is installed but not imported yet, its
+    bundled runtime is loaded first (by path, without importing torch); libpigo_hip.so then binds to it by soname --
+    the same situation as `import torch` before `import pigo_amd`."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system ROCm runtime
+
+
 def load_library():
     """dlopen libpigo_hip.so (in-tree).  Fails loudly when it has not been built -- there is no fallback."""
     global _lib
@@ -71,6 +95,7 @@ def load_library():
     if not os.path.exists(path):
         raise PigoError(f"{path} is missing: build it with `python -m pigo_amd.build` (hipcc, gfx950). "
                         "pigo_amd has no CPU fallback.")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(path)
     vp, i32, dbl, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
     L.pigo_last_error.restype = C.c_char_p

@@ -145,6 +145,7 @@ struct pigo_plan {
     bool tile_ok = false;
     int tab_lds = 0, tab_glb = 0;        // LDS table capacity (trees) of the LDS-pixel / global-pixel classes
     int tile_threads = 256;              // workgroup size of the LDS-pixel classes of k_scan_tile (256 or 512)
+    bool rot_lds = false;                // rotated scan out of LDS tiles (landscape frames: the column clamp nrows-1 stays inside a row)
     bool tab_global = false;             // LDS-pixel classes read their offset tables from global memory (L1) instead of LDS
     size_t deep_lds = 0, deep_lds2 = 0;  // dynamic LDS of the two k_tail_deep launches
     int deep_mid = 0;                    // first launch walks [deep_lo, deep_mid), second [deep_mid, ntrees)
@@ -392,13 +393,13 @@ bool build_tile_stages(pigo_plan &p)
     for (int i = 0; i < nt; ++i) lo = std::min(lo, c.thr[i]);
     ScanArgs &a = p.args;
     a.nh_lds = std::min(nt, std::max(1, env_int("PIGO_NH_LDS", 28)));
-    a.nh_glb = std::min(nt, std::max(1, p.rot ? env_int("PIGO_NH_ROT", 18) : env_int("PIGO_NH_GLB", 28)));
+    a.nh_glb = std::min(nt, std::max(1, (p.rot && !p.rot_lds) ? env_int("PIGO_NH_ROT", 18) : env_int("PIGO_NH_GLB", 28)));
     a.deep_lo = std::min(a.nh_lds, a.nh_glb);
     // LDS table capacity per class: enough for the trees the class walks before handing off; the dense stages'
     // table windows are planned for the smaller of the two so that they fit either
     p.tab_lds = std::min(kTabTrees, std::max(a.nh_lds, 8));
     p.tab_glb = std::min(kTabTrees, std::max(a.nh_glb, 8));
-    a.tab_trees = p.rot ? p.tab_glb : std::min(p.tab_lds, p.tab_glb);
+    a.tab_trees = (p.rot && !p.rot_lds) ? p.tab_glb : std::min(p.tab_lds, p.tab_glb);
     const int cap = a.tab_trees;
     std::vector<int> ends;
     int begin = 0;
@@ -480,7 +481,8 @@ void build_tile_classes(pigo_plan &p)
             pos = end + 1;
         }
     }
-    const bool lds_allowed = !p.rot && (p.key.dim % 4 == 0) && env_int("PIGO_LDS_TILES", 1) != 0;
+    const bool lds_allowed = (!p.rot || p.rot_lds) && (p.key.dim % 4 == 0) && env_int("PIGO_LDS_TILES", 1) != 0;
+    const long long rqc = p.rot ? kQCos[p.angle_idx] : 0, rqs = p.rot ? kQSin[p.angle_idx] : 0;
     const int g_tw_log2 = 6, g_th = env_int("PIGO_GLOBAL_TH", 16);
     const size_t static_slack = 1024;
     const size_t buckets[] = {36u << 10, 48u << 10, 64u << 10, 80u << 10, 104u << 10, 128u << 10, (160u << 10) - static_slack};
@@ -494,12 +496,28 @@ void build_tile_classes(pigo_plan &p)
     std::vector<Pick> picks(p.scales.size());
     for (size_t k = 0; k < p.scales.size(); ++k) {
         ScaleDesc &sd = p.scales[k];
-        const int up = (sd.s + 1) / 2, down = (127 * sd.s) >> 8;
+        int up = (sd.s + 1) / 2, down = (127 * sd.s) >> 8;
+        if (p.rot) {
+            // extent of the rotated sample offsets (dR, dC) of this rung over every node of the cascade (pix_le / k_build_tab):
+            // the LDS tile must cover [centre - up, centre + down] in both directions
+            const long long qc = (long long)sd.s * rqc, qs = (long long)sd.s * rqs;  // pigo.go:159-160
+            long long lo = 0, hi = 0;
+            const pigo_cascade &c = *p.c;
+            for (size_t i = 0; i + 3 < c.codes.size(); i += 2) {  // byte pairs (cr, cc) of both points of every node
+                const long long cr = c.codes[i], cc = c.codes[i + 1];
+                const long long dr = (qc * cr - qs * cc) >> 16, dc = (qs * cr + qc * cc) >> 16;
+                lo = std::min(lo, std::min(dr, dc));
+                hi = std::max(hi, std::max(dr, dc));
+            }
+            up = (int)-lo;
+            down = (int)hi;
+        }
         sd.up = up;
+        sd.down = down;
         sd.pitch = 0;
-        // LDS queues: 1.5 tiles' worth of entries shared by the two ping-pong regions (2 for the rotated scan); an overflow
-        // (stage 0 and stage 1 survivors together exceeding that) is caught on the device
-        const int qb_div = (p.rot || env_int("PIGO_QB_DIV", 2) == 1) ? 1 : 2;
+        // LDS queues: 1.5 tiles' worth of entries shared by the two ping-pong regions; an overflow (stage 0 and stage 1
+        // survivors together exceeding that) is caught on the device
+        const int qb_div = p.rot ? (env_int("PIGO_ROT_QB_DIV", 2) == 1 ? 1 : 2) : (env_int("PIGO_QB_DIV", 2) == 1 ? 1 : 2);
         Pick pk{g_tw_log2, g_th, false, 0, 0, qb_div};
         if (lds_allowed) {
             for (const TileRule &r : rules) {
@@ -510,7 +528,7 @@ void build_tile_classes(pigo_plan &p)
                 const long long ph = (long long)(r.th - 1) * sd.step + up + down + 1;
                 const long long pix = pitch * ph;
                 if (pix > r.max_pix) continue;
-                if ((long long)up * pitch + up > 32767) continue;  // offsets must fit the packed int16 table
+                if ((long long)std::max(up, down) * pitch + std::max(up, down) > 32767) continue;  // offsets must fit the packed int16 table
                 sd.pitch = (int32_t)pitch;
                 pk = Pick{r.tw_log2, r.th, true, (size_t)((pix + 15) / 16 * 16), 0, qb_div};
                 break;
@@ -605,6 +623,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     if (st != PIGO_OK) return st;
 
     p->tab_global = env_int("PIGO_TAB_GLOBAL", 0) != 0;
+    p->rot_lds = p->rot && !p->guard && key.dim % 4 == 0 && env_int("PIGO_ROT_LDS", 1) != 0 && env_int("PIGO_LDS_TILES", 1) != 0;
     p->tile_ok = build_tile_stages(*p);
     build_tile_classes(*p);  // also fills ScaleDesc::pitch / up
 
@@ -632,7 +651,8 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         HIP_TRY(hipMemcpy(p->d_tiles2.p, p->tiles2.data(), p->tiles2.size() * sizeof(uint2), hipMemcpyHostToDevice));
         HIP_TRY(p->d_tabp.alloc((size_t)nscales * c->ntrees * 64));
         const size_t n = (size_t)nscales * c->ntrees * 64;
-        k_build_tabp<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256>>>(c->d_codes.p, p->d_scales.p, p->d_tabp.p, nscales, (int)c->ntrees);
+        k_build_tabp<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256>>>(c->d_codes.p, p->d_scales.p, p->d_tabp.p, nscales, (int)c->ntrees, p->rot ? 1 : 0,
+                                                                                   kQCos[p->angle_idx], kQSin[p->angle_idx]);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
         const int max_dyn = (160 << 10) - 1024;
@@ -641,6 +661,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, false, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, true, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         p->tile_threads = env_int("PIGO_TILE_THREADS", 256) == 512 ? 512 : 256;
         p->side_mode = env_int("PIGO_SIDE_STREAM", 1);
@@ -752,7 +773,10 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
                     k_scan_tile<false, false, false, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
                 }
             } else {
-                k_scan_tile<true, GUARD, false, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
+                if (cls.lds)
+                    k_scan_tile<true, false, true, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
+                else
+                    k_scan_tile<true, GUARD, false, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
             }
         }
         if (fork) {

@@ -118,3 +118,21 @@ def test_cpp_mirror_compiles_and_links(tmp_path):
         assert r.returncode == 4 and "error:" in r.stdout, (r.returncode, r.stdout, r.stderr)
     else:
         assert r.returncode == 0 and "clusters=1 (206,154,261," in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """libpigo_hip.so and PyTorch must share ONE libamdhip64 / libhsa-runtime64: with two HSA runtimes in a process the
+    second one finds no GPUs (seen on the GPU box when pigo_amd was loaded before torch)."""
+    import subprocess
+    import sys
+    prog = ("import sys; sys.path.insert(0, %r)\n"
+            "%s\n"
+            "libs = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l or 'libhsa-runtime64' in l}\n"
+            "print(len([l for l in libs if 'libamdhip64' in l]), len([l for l in libs if 'libhsa-runtime64' in l]))\n")
+    orders = ["from pigo_amd import core; core.load_library(); import torch",
+              "import torch; from pigo_amd import core; core.load_library()",
+              "from pigo_amd import core; core.load_library()"]
+    for o in orders:
+        r = subprocess.run([sys.executable, "-c", prog % (ROOT, o)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        assert r.stdout.split() == ["1", "1"], (o, r.stdout)
