@@ -14,6 +14,7 @@ Rank 0 prints ONE JSON line (see the task contract) with two extra objects:
   roofline      HBM roofline of the dominant kernel (k_scan_head): algorithmic bytes per launch (every frame
                 read once + 16 B per detection) / that kernel's mean duration measured with HIP events on the
                 launch stream; peak 8.0 TB/s.
+  single_frame  BASELINE configs[1] taken literally: one 1080p frame per call, HBM-resident and from a host buffer.
   puploc        side measurement of the RunDetector kernel (4096 requests x 63 perturbations): requests/s.
   gray          side measurement of the RgbToGrayscale kernel (the streaming step in front of the scan): GB/s vs 8 TB/s.
   cpu_baseline  the CPU oracle (a C restatement of the reference's Go path -- the Go toolchain is absent) timed
@@ -56,7 +57,8 @@ def parse_args():
     ap.add_argument("--no-cluster", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gray", action="store_true", help="skip the RgbToGrayscale (row f1) side measurement")
+    ap.add_argument("--no-gray", action="store_true", help="skip the side measurements (RgbToGrayscale, RunDetector, single frame)")
+    ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call leg (keeps kernel profiles per-batch)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto, ~15 s)")
     return ap.parse_args()
 
@@ -200,6 +202,36 @@ def main():
         torch.cuda.synchronize()
         cluster_ms = cev[0].elapsed_time(cev[1]) / reps
 
+    # ---- BASELINE configs[1] as stated: ONE 1080p frame.  (a) resident in HBM, back-to-back launches of the plan;
+    # (b) RunCascade on a host buffer: H2D of the frame, scan, D2H of the detections (PCIe-inclusive; never `value`)
+    single_leg = None
+    if rank == 0 and not args.no_gray and not args.no_single_frame:
+        plan1 = batch.ScanPlan(pg, args.rows, args.cols, MinSize=args.min_size, MaxSize=args.max_size, ShiftFactor=args.shift,
+                               ScaleFactor=args.scale, angle=args.angle, max_frames=1, det_cap=args.det_cap)
+        d1, c1 = plan1.alloc_outputs(1)
+        for _ in range(5):
+            plan1.run(d_frames[:1], d1, c1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(100):
+            plan1.run(d_frames[:1], d1, c1)
+        torch.cuda.synchronize()
+        dev_ms = (time.perf_counter() - t1) / 100 * 1e3
+        plan1.status()
+        cp1 = core.CascadeParams(MinSize=args.min_size, MaxSize=args.max_size, ShiftFactor=args.shift, ScaleFactor=args.scale,
+                                 ImageParams=core.ImageParams(Pixels=frames[0], Rows=args.rows, Cols=args.cols, Dim=args.cols))
+        for _ in range(3):
+            pg.RunCascade(cp1, args.angle)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            pg.RunCascade(cp1, args.angle)
+        host_ms = (time.perf_counter() - t1) / 20 * 1e3
+        w1 = int(info.windows_per_frame)
+        single_leg = {"hbm_resident_ms": round(dev_ms, 4), "hbm_resident_mwindows_per_s": round(w1 / dev_ms / 1e3, 1),
+                      "host_buffer_ms": round(host_ms, 4), "host_buffer_mwindows_per_s": round(w1 / host_ms / 1e3, 1),
+                      "note": "one frame per call; host_buffer includes PCIe H2D/D2H and two synchronisations"}
+        del plan1
+
     # ---- side measurement, outside the timed region: RgbToGrayscale (core/grayscale.go:8-23), the streaming step in
     # front of the scan.  RGBA frames {g,g,g,255} built on the GPU from the gray batch; the kernel must give them back.
     gray_leg = None
@@ -314,6 +346,7 @@ def main():
                 "note": "compulsory bytes only (each frame read once); the kernel is gather/issue bound, see DESIGN.md",
             },
         }
+        out["single_frame"] = single_leg
         out["gray"] = gray_leg
         out["puploc"] = pup_leg
         if n_gpus == 1 and not args.no_cpu_baseline:

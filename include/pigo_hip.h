@@ -187,7 +187,8 @@ pigo_status pigo_plan_info(const pigo_plan *p, pigo_plan_info_t *info);
 pigo_status pigo_plan_set_variant(pigo_plan *p, int variant);
 
 /* Asynchronous scan of `nframes` (<= max_frames) device-resident frames.  `d_frames` points to
- * nframes consecutive frames of `frame_stride` bytes each (>= rows*dim) in device memory.
+ * nframes consecutive frames of `frame_stride` bytes each (>= rows*dim) in device memory; when dim is a
+ * multiple of 4 the pointer and the stride must be too (frames are copied as aligned dwords).
  * Enqueues on `stream` (a hipStream_t, NULL = default stream):
  *     d_dets   [nframes][det_cap] pigo_det, reference order per frame
  *     d_counts [nframes] int32: detections found (if > det_cap the frame's list is truncated)

@@ -835,6 +835,8 @@ pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame
     if (nframes == 0) return PIGO_OK;
     if (!d_frames || !d_dets || !d_counts) return fail(PIGO_ERR_PARAM, "NULL device pointer");
     if (frame_stride < (size_t)p->key.rows * p->key.dim) return fail(PIGO_ERR_PARAM, "frame_stride smaller than rows*dim");
+    if (p->key.dim % 4 == 0 && (((uintptr_t)d_frames | (uintptr_t)frame_stride) & 3u))  // the tile / patch copies move aligned dwords
+        return fail(PIGO_ERR_PARAM, "d_frames and frame_stride must be multiples of 4 bytes when dim is");
     HIP_TRY(hipSetDevice(p->c->device));
     HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nframes * 4, s));
     p->last_nframes = nframes;

@@ -1,14 +1,6 @@
+# the rocprofv3 passes of gpu_round1_final.sh only
 # Round-1 measurement: parity suite, smoke, the default bench line, the RCCL path at world size 1, rocprofv3 trace + PMC passes
 mkdir -p gpurun_out/prof_r1f && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-nproc > gpurun_out/prof_r1f/host.txt; (rocminfo | grep -m3 "Marketing Name" ) >> gpurun_out/prof_r1f/host.txt 2>&1
-timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_gpu.log | cut -c1-200
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
-timeout 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench rc=$?"; cat gpurun_out/bench_default.json
-timeout 300 python bench.py --force-dist --frames 32 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_dist1.json 2> gpurun_out/bench_dist1.err; echo "dist1 rc=$?"; cut -c1-300 gpurun_out/bench_dist1.json; tail -3 gpurun_out/bench_dist1.err
-timeout 300 python bench.py --kind noise --no-cpu-baseline > gpurun_out/bench_noise.json 2> gpurun_out/bench_noise.err; echo "noise rc=$?"; cut -c1-400 gpurun_out/bench_noise.json
-timeout 300 python bench.py --angle 0.8 --no-cpu-baseline > gpurun_out/bench_rot.json 2> gpurun_out/bench_rot.err; echo "rot rc=$?"; cut -c1-400 gpurun_out/bench_rot.json
-timeout 300 python bench.py --rows 2160 --cols 3840 --min-size 20 --max-size 2000 --shift 0.05 --scale 1.05 --frames 8 --det-cap 32768 --gather-cap 64 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_4k.json 2> gpurun_out/bench_4k.err; echo "4k rc=$?"; cut -c1-400 gpurun_out/bench_4k.json; tail -2 gpurun_out/bench_4k.err
-python scripts/single_frame_latency.py 2>&1 | grep "single 1080p" | tee gpurun_out/single_frame.txt
 B="python bench.py --frames 64 --steps 5 --warmup 2 --no-cpu-baseline --no-single-frame"
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r1f/trace -o t -- $B > gpurun_out/prof_r1f/trace.log 2>&1; echo "trace rc=$?"
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_r1f/pmc_fetch -o p -- $B > gpurun_out/prof_r1f/pmc_fetch.log 2>&1; echo "pmc_fetch rc=$?"
@@ -19,4 +11,3 @@ T=gpurun_out/prof_r1f
 python scripts/summarize_prof.py "round 1 final (see scripts/gpu_round1_final.sh): python bench.py --frames 64 --steps 5 --warmup 2 --no-cpu-baseline -- 64 x 1080p SYN-FACES frames per step; 12 scan steps per run (2 warm-up + 5 timed + 5 per-kernel event reps) + the gray / puploc side legs" $T/trace/t_results.db $T/pmc_fetch/p_results.db $T/pmc_write/p_results.db $T/pmc_sq/p_results.db $T/pmc_sq2/p_results.db > gpurun_out/final_summary.txt 2>gpurun_out/final_summary.err; echo "summary rc=$?"; head -22 gpurun_out/final_summary.txt | cut -c1-150
 python scripts/make_traffic.py $T/pmc_fetch/p_results.db $T/pmc_write/p_results.db 12 64 > gpurun_out/traffic.json 2>gpurun_out/traffic.err; echo "traffic rc=$?"; grep hbm_bytes gpurun_out/traffic.json
 rm -rf $T/trace $T/pmc_fetch $T/pmc_write $T/pmc_sq $T/pmc_sq2
-du -sh gpurun_out/prof_r1f
