@@ -59,7 +59,8 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB
+    """In-tree libpigo_hip.so; PIGO_HIP_LIB overrides it (A/B runs of experimental builds)."""
+    return os.environ.get("PIGO_HIP_LIB") or _build.LIB
 
 
 def _share_hip_runtime_with_torch():
