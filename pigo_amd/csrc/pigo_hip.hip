@@ -171,8 +171,17 @@ struct pigo_plan {
     hipEvent_t ev_join2[3] = {nullptr, nullptr, nullptr};
     int side_mode = 1;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // chunked pipeline: the deep tail of chunk c runs on `tail_stream` next to the tile kernels of chunk c+1 (two queue sets)
+    int pipe_chunks = 0;                 // 0 = automatic
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t ev_tiles[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
     ~pigo_plan()
     {
+        for (int i = 0; i < 2; ++i) {
+            if (ev_tiles[i]) (void)hipEventDestroy(ev_tiles[i]);
+            if (ev_tail[i]) (void)hipEventDestroy(ev_tail[i]);
+        }
+        if (tail_stream) (void)hipStreamDestroy(tail_stream);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -584,7 +593,7 @@ pigo_status plan_alloc_batch(pigo_plan &p, int max_frames, int det_cap)
     qcap = (qcap + kTailChunk - 1) / kTailChunk * kTailChunk;
     p.qcap = qcap;
     HIP_TRY(p.d_queue.alloc((size_t)qcap * max_frames));
-    HIP_TRY(p.d_qcount.alloc(std::max(max_frames, 16)));
+    HIP_TRY(p.d_qcount.alloc(std::max(max_frames, 32)));  // [0..7] per-XCD queues, [8] second-level queue; [16..24] the second set
     p.qcap2 = std::max<long long>(4096, (qcap * (long long)max_frames) / 8);
     HIP_TRY(p.d_queue2.alloc((size_t)p.qcap2));
     HIP_TRY(p.d_raw.alloc((size_t)det_cap * max_frames));
@@ -670,6 +679,14 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
                 HIP_TRY(hipStreamCreateWithFlags(&p->side2[i], hipStreamNonBlocking));
                 HIP_TRY(hipEventCreateWithFlags(&p->ev_join2[i], hipEventDisableTiming));
             }
+        p->pipe_chunks = std::max(0, std::min(16, env_int("PIGO_PIPE_CHUNKS", 0)));  // 0 = automatic: about 32 frames per chunk
+        if (p->pipe_chunks != 1) {
+            HIP_TRY(hipStreamCreateWithFlags(&p->tail_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(hipEventCreateWithFlags(&p->ev_tiles[i], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&p->ev_tail[i], hipEventDisableTiming));
+            }
+        }
         if (p->side_mode) {
             HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
@@ -722,96 +739,145 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     return PIGO_OK;
 }
 
+// variant 2, first half of a (chunk of a) batch: one k_scan_tile launch per tile class; `xcd_cap` = entries per XCD queue
+template <bool ROT, bool GUARD, class Mark>
+void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipStream_t s, Mark &mark)
+{
+    // fork: classes that gather from global memory go to the side stream when the plan also has LDS-tile classes
+    bool has_lds = false, has_glb = false;
+    for (const pigo_plan::TileClass &cls : p.classes)
+        if (cls.ntiles) (cls.lds ? has_lds : has_glb) = true;
+    const bool fork = p.side && has_lds && has_glb && !p.profiling;
+    const bool fork_all = fork && p.side_mode == 2;
+    if (fork) {
+        (void)hipEventRecord(p.ev_fork, s);
+        (void)hipStreamWaitEvent(p.side, p.ev_fork, 0);
+        if (fork_all)
+            for (int i = 0; i < 3; ++i) (void)hipStreamWaitEvent(p.side2[i], p.ev_fork, 0);
+    }
+    int lds_idx = 0;
+    for (const pigo_plan::TileClass &cls : p.classes) {
+        if (cls.ntiles == 0) continue;
+        hipStream_t cs = (fork && !cls.lds) ? p.side : s;
+        if (fork_all && cls.lds) {
+            if (lds_idx > 0 && lds_idx <= 3) cs = p.side2[lds_idx - 1];
+            ++lds_idx;
+        }
+        ScanArgs ca = a;
+        ca.qcap = xcd_cap;
+        ca.cls_tile0 = cls.tile0;
+        ca.cls_ntiles = cls.ntiles;
+        ca.tw_log2 = cls.tw_log2;
+        ca.th = cls.th;
+        ca.nwin = cls.nwin;
+        ca.tab_trees = cls.lds ? p.tab_lds : p.tab_glb;
+        ca.qb_div = cls.qb_div;
+        const uint32_t grid = (uint32_t)a.nframes * cls.ntiles;
+        mark(cls.lds ? "scan_tile_lds" : "scan_tile_glb");
+        const bool wide = p.tile_threads == 512;
+        if constexpr (!ROT) {
+            if (cls.lds) {
+                if (p.tab_global) {
+                    ca.tab_trees = 0;  // no table region in LDS
+                    k_scan_tile<false, false, true, 256, false><<<grid, 256, cls.dyn_lds, cs>>>(ca);
+                } else if (wide) {
+                    k_scan_tile<false, false, true, 512, true><<<grid, 512, cls.dyn_lds, cs>>>(ca);
+                } else {
+                    k_scan_tile<false, false, true, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
+                }
+            } else {
+                k_scan_tile<false, false, false, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
+            }
+        } else {
+            if (cls.lds)
+                k_scan_tile<true, false, true, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
+            else
+                k_scan_tile<true, GUARD, false, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
+        }
+    }
+    if (fork) {
+        (void)hipEventRecord(p.ev_join, p.side);
+        (void)hipStreamWaitEvent(s, p.ev_join, 0);
+        if (fork_all)
+            for (int i = 0; i < 3; ++i) {
+                (void)hipEventRecord(p.ev_join2[i], p.side2[i]);
+                (void)hipStreamWaitEvent(s, p.ev_join2[i], 0);
+            }
+    }
+}
+
+// variant 2, second half: the two k_tail_deep launches over the queues `a.queue` / `a.qcount` (8 per-XCD queues of xcd_cap
+// entries) with `queue2` (cap2 entries, counter a.qcount[8]) in between
+template <bool ROT, bool GUARD, class Mark>
+void launch_tail(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry *queue2, uint32_t cap2, hipStream_t s, Mark &mark)
+{
+    if (a.deep_lo >= a.ntrees) return;
+    mark("tail_deep");
+    ScanArgs ta = a;
+    ta.qcap = xcd_cap;
+    ta.nqueues = 8;
+    ta.deep_hi = p.deep_mid;
+    ta.queue2 = queue2;
+    ta.qcount2 = a.qcount + 8;
+    ta.qcap2 = cap2;
+    k_tail_deep<ROT, GUARD><<<(p.deep_lds * 2 <= (size_t)(158 << 10)) ? 512 : 256, kDeepThreads, p.deep_lds, s>>>(ta);
+    if (p.deep_mid < a.ntrees) {
+        mark("tail_deep2");
+        ScanArgs tb = a;
+        tb.queue = queue2;
+        tb.nqueues = 1;
+        tb.qcount = a.qcount + 8;
+        tb.qcap = cap2;
+        tb.deep_lo = p.deep_mid;
+        tb.deep_hi = a.ntrees;
+        tb.queue2 = nullptr;
+        tb.qcount2 = nullptr;
+        tb.qcap2 = 0;
+        k_tail_deep<ROT, GUARD><<<256, kDeepThreads, p.deep_lds2, s>>>(tb);
+    }
+}
+
 template <bool ROT, bool GUARD, class Mark>
 void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t s, Mark &mark)
 {
     const uint32_t nb = (uint32_t)a.nframes * (uint32_t)a.ntiles;
     if (variant == 2) {
-        // fork: classes that gather from global memory go to the side stream when the plan also has LDS-tile classes
-        bool has_lds = false, has_glb = false;
-        for (const pigo_plan::TileClass &cls : p.classes)
-            if (cls.ntiles) (cls.lds ? has_lds : has_glb) = true;
-        const bool fork = p.side && has_lds && has_glb && !p.profiling;
-        const bool fork_all = fork && p.side_mode == 2;
-        if (fork) {
-            (void)hipEventRecord(p.ev_fork, s);
-            (void)hipStreamWaitEvent(p.side, p.ev_fork, 0);
-            if (fork_all)
-                for (int i = 0; i < 3; ++i) (void)hipStreamWaitEvent(p.side2[i], p.ev_fork, 0);
-        }
-        int lds_idx = 0;
-        for (const pigo_plan::TileClass &cls : p.classes) {
-            if (cls.ntiles == 0) continue;
-            hipStream_t cs = (fork && !cls.lds) ? p.side : s;
-            if (fork_all && cls.lds) {
-                if (lds_idx > 0 && lds_idx <= 3) cs = p.side2[lds_idx - 1];
-                ++lds_idx;
+        const long long qtotal = p.qcap * (long long)p.max_frames;  // entries of d_queue
+        const int want_chunks = p.pipe_chunks > 0 ? p.pipe_chunks : std::max(2, std::min(8, (a.nframes + 31) / 32));
+        const int chunks = (p.tail_stream && !p.profiling && a.nframes >= 16 && a.deep_lo < a.ntrees) ? want_chunks : 1;
+        if (chunks <= 1) {
+            const uint32_t xcd_cap = (uint32_t)std::min<long long>(qtotal / 8, 0xffffffffLL);
+            launch_tiles<ROT, GUARD>(p, a, xcd_cap, s, mark);
+            launch_tail<ROT, GUARD>(p, a, xcd_cap, p.d_queue2.p, (uint32_t)p.qcap2, s, mark);
+        } else {
+            // Frames are independent, so the batch is cut into chunks (multiples of 8 frames: the XCD dealing) and the deep
+            // tail of chunk c -- latency-bound, few waves -- runs on its own stream while the tile kernels of chunk c+1 --
+            // issue-bound -- fill the rest of the machine.  Two queue sets alternate; everything joins `s` before returning.
+            const int per = (((a.nframes + chunks - 1) / chunks) + 7) & ~7;
+            const long long half = qtotal / 2, half2 = p.qcap2 / 2;
+            const uint32_t xcd_cap = (uint32_t)std::min<long long>(half / 8, 0xffffffffLL);
+            bool used[2] = {false, false};
+            int c = 0;
+            for (int f0 = 0; f0 < a.nframes; f0 += per, ++c) {
+                const int set = c & 1;
+                ScanArgs ac = a;
+                ac.nframes = std::min(per, a.nframes - f0);
+                ac.frames = a.frames + (size_t)f0 * a.frame_stride;
+                ac.counts = a.counts + f0;
+                ac.raw = a.raw + (size_t)f0 * a.det_cap;
+                ac.queue = p.d_queue.p + (size_t)set * half;
+                ac.qcount = p.d_qcount.p + 16 * set;
+                if (used[set]) (void)hipStreamWaitEvent(s, p.ev_tail[set], 0);  // the tail of chunk c-2 is done with this set
+                (void)hipMemsetAsync(ac.qcount, 0, 16 * sizeof(uint32_t), s);
+                launch_tiles<ROT, GUARD>(p, ac, xcd_cap, s, mark);
+                (void)hipEventRecord(p.ev_tiles[set], s);
+                (void)hipStreamWaitEvent(p.tail_stream, p.ev_tiles[set], 0);
+                launch_tail<ROT, GUARD>(p, ac, xcd_cap, p.d_queue2.p + (size_t)set * half2, (uint32_t)half2, p.tail_stream, mark);
+                (void)hipEventRecord(p.ev_tail[set], p.tail_stream);
+                used[set] = true;
             }
-            ScanArgs ca = a;
-            ca.qcap = (uint32_t)std::min<long long>(p.qcap * (long long)p.max_frames / 8, 0xffffffffLL);  // per XCD queue
-            ca.cls_tile0 = cls.tile0;
-            ca.cls_ntiles = cls.ntiles;
-            ca.tw_log2 = cls.tw_log2;
-            ca.th = cls.th;
-            ca.nwin = cls.nwin;
-            ca.tab_trees = cls.lds ? p.tab_lds : p.tab_glb;
-            ca.qb_div = cls.qb_div;
-            const uint32_t grid = (uint32_t)a.nframes * cls.ntiles;
-            mark(cls.lds ? "scan_tile_lds" : "scan_tile_glb");
-            const bool wide = p.tile_threads == 512;
-            if constexpr (!ROT) {
-                if (cls.lds) {
-                    if (p.tab_global) {
-                        ca.tab_trees = 0;  // no table region in LDS
-                        k_scan_tile<false, false, true, 256, false><<<grid, 256, cls.dyn_lds, cs>>>(ca);
-                    } else if (wide) {
-                        k_scan_tile<false, false, true, 512, true><<<grid, 512, cls.dyn_lds, cs>>>(ca);
-                    } else {
-                        k_scan_tile<false, false, true, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
-                    }
-                } else {
-                    k_scan_tile<false, false, false, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
-                }
-            } else {
-                if (cls.lds)
-                    k_scan_tile<true, false, true, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
-                else
-                    k_scan_tile<true, GUARD, false, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
-            }
-        }
-        if (fork) {
-            (void)hipEventRecord(p.ev_join, p.side);
-            (void)hipStreamWaitEvent(s, p.ev_join, 0);
-            if (fork_all)
-                for (int i = 0; i < 3; ++i) {
-                    (void)hipEventRecord(p.ev_join2[i], p.side2[i]);
-                    (void)hipStreamWaitEvent(s, p.ev_join2[i], 0);
-                }
-        }
-        if (a.deep_lo < a.ntrees) {
-            mark("tail_deep");
-            ScanArgs ta = a;
-            ta.qcap = (uint32_t)std::min<long long>(p.qcap * (long long)p.max_frames / 8, 0xffffffffLL);
-            ta.nqueues = 8;
-            ta.deep_hi = p.deep_mid;
-            ta.queue2 = p.d_queue2.p;
-            ta.qcount2 = p.d_qcount.p + 8;
-            ta.qcap2 = (uint32_t)p.qcap2;
-            k_tail_deep<ROT, GUARD><<<(p.deep_lds * 2 <= (size_t)(158 << 10)) ? 512 : 256, kDeepThreads, p.deep_lds, s>>>(ta);
-            if (p.deep_mid < a.ntrees) {
-                mark("tail_deep2");
-                ScanArgs tb = a;
-                tb.queue = p.d_queue2.p;
-                tb.nqueues = 1;
-                tb.qcount = p.d_qcount.p + 8;
-                tb.qcap = (uint32_t)p.qcap2;
-                tb.deep_lo = p.deep_mid;
-                tb.deep_hi = a.ntrees;
-                tb.queue2 = nullptr;
-                tb.qcount2 = nullptr;
-                tb.qcap2 = 0;
-                k_tail_deep<ROT, GUARD><<<256, kDeepThreads, p.deep_lds2, s>>>(tb);
-            }
+            for (int set = 0; set < 2; ++set)
+                if (used[set]) (void)hipStreamWaitEvent(s, p.ev_tail[set], 0);
         }
     } else if (variant == 1) {
         mark("scan_head");

@@ -211,6 +211,30 @@ def test_batch_api_matches_single_frame_and_is_order_stable(pg, orc):
                 assert_same_dets(srt[f], w, f"batch sorted frame {f}", Q_TOL_RAW)
 
 
+@pytest.mark.parametrize("chunks,angle", [(2, 0.0), (3, 0.0), (1, 0.0), (0, 0.0), (2, 0.6)])
+def test_chunked_pipeline_large_batches(pg, orc, chunks, angle, monkeypatch):
+    """Batches of >= 16 frames are cut into chunks whose deep tail overlaps the next chunk's tile kernels (two queue sets,
+    a tail stream).  29 frames = chunks of 16 + 13 (or 16 + 8 + 5): ragged last chunk, fewer than 8 frames in it, a second
+    run on the same buffers, and the result must not depend on the chunk count."""
+    import torch
+    from pigo_amd import batch
+    monkeypatch.setenv("PIGO_PIPE_CHUNKS", str(chunks))
+    n, rows, cols = 29, 240, 320
+    frames = np.concatenate([synth.make_frames("faces", n - 6, rows, cols, seed=5), synth.make_frames("noise", 6, rows, cols, seed=6)])
+    d_frames = torch.from_numpy(frames).cuda()
+    want = [orc.run_cascade(frames[f], rows, cols, cols, 20, 300, 0.1, 1.1, angle) for f in range(n)]
+    plan = batch.ScanPlan(pg, rows, cols, MinSize=20, MaxSize=300, ShiftFactor=0.1, ScaleFactor=1.1, angle=angle, max_frames=32, det_cap=1024)
+    dets, counts = plan.alloc_outputs(n)
+    for rep in range(3):
+        plan.run(d_frames, dets, counts)
+        torch.cuda.synchronize()
+        plan.status()
+        got = batch.dets_to_numpy(dets, counts)
+        for f in range(n):
+            assert_same_dets(got[f], want[f], f"chunks={chunks} angle={angle} frame {f} rep{rep}", Q_TOL_RAW)
+    assert sum(len(w) for w in want) > (50 if angle == 0.0 else 5)
+
+
 @pytest.mark.parametrize("rules", ["5,16,20480", "6,32,40000;6,8,60000", "6,8,4096"])
 def test_tile_geometry_rules(orc, rules, monkeypatch):
     """Variant 2 with unusual tile geometries (32-wide tiles, 2048-window tiles, almost everything on the
