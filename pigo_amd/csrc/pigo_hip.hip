@@ -681,7 +681,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
             }
         p->pipe_chunks = std::max(0, std::min(16, env_int("PIGO_PIPE_CHUNKS", 0)));  // 0 = automatic: about 32 frames per chunk
         if (p->pipe_chunks != 1) {
-            HIP_TRY(hipStreamCreateWithFlags(&p->tail_stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&p->tail_stream, hipStreamNonBlocking));  // (a high-priority stream measured no different)
             for (int i = 0; i < 2; ++i) {
                 HIP_TRY(hipEventCreateWithFlags(&p->ev_tiles[i], hipEventDisableTiming));
                 HIP_TRY(hipEventCreateWithFlags(&p->ev_tail[i], hipEventDisableTiming));
