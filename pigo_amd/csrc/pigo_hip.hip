@@ -445,9 +445,9 @@ bool build_tile_stages(pigo_plan &p)
         ends.swap(m);
     }
     a.n_stages = (int)ends.size();
-    // two launches of k_tail_deep: the first two passes (128 trees) with a small code table -> two workgroups per CU;
+    // two launches of k_tail_deep: the first three passes (192 trees; measured plateau 160..256) with their codes in LDS;
     // the few windows that survive them continue in a second launch holding the remaining codes
-    p.deep_mid = std::min(nt, a.deep_lo + std::max(64, env_int("PIGO_DEEP_SPLIT", 128)));
+    p.deep_mid = std::min(nt, a.deep_lo + std::max(64, env_int("PIGO_DEEP_SPLIT", 192)));
     p.deep_lds = (size_t)(p.deep_mid - a.deep_lo) * kCodeStride * 4 + (size_t)kDeepWaves * kPatchBytes;
     p.deep_lds2 = (size_t)(nt - p.deep_mid) * kCodeStride * 4 + (size_t)kDeepWaves * kPatchBytes;
     if (p.deep_lds > (size_t)(160 << 10) - 1024 || p.deep_lds2 > (size_t)(160 << 10) - 1024) return false;  // codes must fit one CU's LDS
