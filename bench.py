@@ -110,6 +110,11 @@ def cpu_baseline(args, frames, windows_per_frame):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line, the JSON record: native libraries (RCCL prints its version banner to stdout) and
+    # anything else that writes to fd 1 go to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from pigo_amd import batch, core, distributed, synth
@@ -353,7 +358,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, frames, wpf)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
