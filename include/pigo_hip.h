@@ -226,7 +226,9 @@ pigo_status pigo_plan_debug_stats(pigo_plan *p, uint64_t *out, int n);
 /* Debug only: raw per-iteration trace of late mode for 16 tiles (n >= 4096 words). */
 pigo_status pigo_plan_debug_trace(pigo_plan *p, uint64_t *out, int n);
 
-/* Device statistics of the most recent run (valid after synchronising): survivor-queue entries. */
+/* Device statistics of the most recent run (valid after synchronising): survivor-queue entries.  Batches of >= 16
+ * frames are pipelined in chunks over two queue sets; the figure then covers the last chunk that used the first set
+ * (bench.py reads it after an un-pipelined profiling run). */
 pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n);
 
 #ifdef __cplusplus
