@@ -197,9 +197,9 @@ pigo_status pigo_plan_run(pigo_plan *p, const uint8_t *d_frames, size_t frame_st
                           int32_t *d_counts, void *stream);
 
 /* Asynchronous per-frame ClusterDetections of the lists produced by pigo_plan_run (same stream):
- * sorts each frame's list by (Q ascending, reference index) -- a STABLE order, which equals Go's
- * sort.Slice whenever a frame has no tied Q values; d_ties[f] (may be NULL) receives the number of
- * adjacent equal-Q pairs so callers can detect the unpinned case -- then clusters on the GPU.
+ * sorts each frame's list by ascending Q exactly like the reference's sort.Slice -- a stable order when
+ * the frame has no tied Q values (then the two coincide), Go's pdqsort restated on the device otherwise;
+ * d_ties[f] (may be NULL) receives the number of tied detections -- then clusters on the GPU.
  *     d_sorted   [nframes][det_cap] the frame's detections, sorted (what the reference leaves in the caller's slice)
  *     d_clusters [nframes][det_cap], d_ccounts [nframes] */
 pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, const int32_t *d_counts, int nframes, double iou_threshold,

@@ -153,6 +153,7 @@ struct pigo_plan {
     long long qcap2 = 0;
     DevBuf<QEntry> d_queue;
     DevBuf<uint32_t> d_qcount;
+    DevBuf<int32_t> d_ties;              // per-frame tie counts when the caller does not ask for them
     DevBuf<RawDet> d_raw;
     DevBuf<int32_t> d_flags;
     DevBuf<float> d_mq;
@@ -598,6 +599,7 @@ pigo_status plan_alloc_batch(pigo_plan &p, int max_frames, int det_cap)
     HIP_TRY(p.d_queue2.alloc((size_t)p.qcap2));
     HIP_TRY(p.d_raw.alloc((size_t)det_cap * max_frames));
     HIP_TRY(p.d_mq.alloc((size_t)det_cap * max_frames));
+    HIP_TRY(p.d_ties.alloc(max_frames));
     return PIGO_OK;
 }
 
@@ -1118,9 +1120,13 @@ extern "C" pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, c
     if (p->det_cap > 65536) return fail(PIGO_ERR_PARAM, "GPU clustering supports det_cap <= 65536");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(p->c->device));
-    if (d_ties) HIP_TRY(hipMemsetAsync(d_ties, 0, (size_t)nframes * 4, s));
+    if (!d_ties) d_ties = p->d_ties.p;
+    HIP_TRY(hipMemsetAsync(d_ties, 0, (size_t)nframes * 4, s));
     dim3 grid((unsigned)((p->det_cap + kThreads - 1) / kThreads), (unsigned)nframes);
     k_sort_by_q<<<grid, kThreads, 0, s>>>(d_dets, d_counts, p->det_cap, d_sorted, d_ties);
+    // frames with tied Q values: redo the sort with Go's own (unstable) algorithm so that the tie order -- and with it the
+    // seed order and the float32 sum order of ClusterDetections -- is the reference's
+    k_gosort_ties<<<nframes, 64, 0, s>>>(d_dets, d_counts, p->det_cap, d_ties, d_sorted);
     if (p->det_cap <= 256 * 64)
         k_cluster<256><<<nframes, 256, 0, s>>>(d_sorted, d_counts, p->det_cap, iou_threshold, d_clusters, d_ccounts, p->d_mq.p);
     else
@@ -1129,224 +1135,6 @@ extern "C" pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, c
     return PIGO_OK;
 }
 
-// Go's sort.Slice (sort/zsortfunc.go, Go 1.19-1.22: pattern-defeating quicksort) specialised to
-// `detections[i].Q < detections[j].Q`  (pigo.go:264-266).  It is unstable, so the order of tied Q values
-// is a property of this exact algorithm; see DESIGN.md "Ties".
-namespace gosort {
-
-struct Data {
-    pigo_det *d;
-    bool less(long i, long j) const { return d[i].q < d[j].q; }
-    void swap(long i, long j) const { std::swap(d[i], d[j]); }
-};
-
-void insertion_sort(const Data &x, long a, long b)
-{
-    for (long i = a + 1; i < b; ++i)
-        for (long j = i; j > a && x.less(j, j - 1); --j) x.swap(j, j - 1);
-}
-
-void sift_down(const Data &x, long lo, long hi, long first)
-{
-    long root = lo;
-    for (;;) {
-        long child = 2 * root + 1;
-        if (child >= hi) return;
-        if (child + 1 < hi && x.less(first + child, first + child + 1)) ++child;
-        if (!x.less(first + root, first + child)) return;
-        x.swap(first + root, first + child);
-        root = child;
-    }
-}
-
-void heap_sort(const Data &x, long a, long b)
-{
-    const long first = a, lo = 0, hi = b - a;
-    for (long i = (hi - 1) / 2; i >= 0; --i) sift_down(x, i, hi, first);
-    for (long i = hi - 1; i >= 0; --i) {
-        x.swap(first, first + i);
-        sift_down(x, lo, i, first);
-    }
-}
-
-long partition(const Data &x, long a, long b, long pivot, bool &already)
-{
-    x.swap(a, pivot);
-    long i = a + 1, j = b - 1;
-    while (i <= j && x.less(i, a)) ++i;
-    while (i <= j && !x.less(j, a)) --j;
-    if (i > j) {
-        x.swap(j, a);
-        already = true;
-        return j;
-    }
-    x.swap(i, j);
-    ++i;
-    --j;
-    for (;;) {
-        while (i <= j && x.less(i, a)) ++i;
-        while (i <= j && !x.less(j, a)) --j;
-        if (i > j) break;
-        x.swap(i, j);
-        ++i;
-        --j;
-    }
-    x.swap(j, a);
-    already = false;
-    return j;
-}
-
-long partition_equal(const Data &x, long a, long b, long pivot)
-{
-    x.swap(a, pivot);
-    long i = a + 1, j = b - 1;
-    for (;;) {
-        while (i <= j && !x.less(a, i)) ++i;
-        while (i <= j && x.less(a, j)) --j;
-        if (i > j) break;
-        x.swap(i, j);
-        ++i;
-        --j;
-    }
-    return i;
-}
-
-bool partial_insertion_sort(const Data &x, long a, long b)
-{
-    const long max_steps = 5, shortest_shifting = 50;
-    long i = a + 1;
-    for (long step = 0; step < max_steps; ++step) {
-        while (i < b && !x.less(i, i - 1)) ++i;
-        if (i == b) return true;
-        if (b - a < shortest_shifting) return false;
-        x.swap(i, i - 1);
-        if (i - a >= 2)
-            for (long j = i - 1; j >= 1; --j) {
-                if (!x.less(j, j - 1)) break;
-                x.swap(j, j - 1);
-            }
-        if (b - i >= 2)
-            for (long j = i + 1; j < b; ++j) {
-                if (!x.less(j, j - 1)) break;
-                x.swap(j, j - 1);
-            }
-    }
-    return false;
-}
-
-int bits_len(unsigned long long v)
-{
-    int n = 0;
-    for (; v; v >>= 1) ++n;
-    return n;
-}
-
-void break_patterns(const Data &x, long a, long b)
-{
-    const long length = b - a;
-    if (length >= 8) {
-        unsigned long long rnd = (unsigned long long)length;
-        const unsigned long long modulus = 1ull << bits_len((unsigned long long)length);
-        const long idx = a + (length / 4) * 2 - 1;
-        for (long i = 0; i < 3; ++i) {
-            rnd ^= rnd << 13;
-            rnd ^= rnd >> 7;
-            rnd ^= rnd << 17;
-            long other = (long)(rnd & (modulus - 1));
-            if (other >= length) other -= length;
-            x.swap(idx - 1 + i, a + other);
-        }
-    }
-}
-
-void order2(const Data &x, long &a, long &b, long &swaps)
-{
-    if (x.less(b, a)) {
-        ++swaps;
-        std::swap(a, b);
-    }
-}
-
-long median(const Data &x, long a, long b, long c, long &swaps)
-{
-    order2(x, a, b, swaps);
-    order2(x, b, c, swaps);
-    order2(x, a, b, swaps);
-    return b;
-}
-
-enum Hint { kUnknown, kIncreasing, kDecreasing };
-
-long choose_pivot(const Data &x, long a, long b, Hint &hint)
-{
-    const long shortest_ninther = 50, max_swaps = 4 * 3;
-    const long l = b - a;
-    long swaps = 0;
-    long i = a + l / 4 * 1, j = a + l / 4 * 2, k = a + l / 4 * 3;
-    if (l >= 8) {
-        if (l >= shortest_ninther) {
-            i = median(x, i - 1, i, i + 1, swaps);
-            j = median(x, j - 1, j, j + 1, swaps);
-            k = median(x, k - 1, k, k + 1, swaps);
-        }
-        j = median(x, i, j, k, swaps);
-    }
-    hint = swaps == 0 ? kIncreasing : swaps == max_swaps ? kDecreasing : kUnknown;
-    return j;
-}
-
-void reverse_range(const Data &x, long a, long b)
-{
-    for (long i = a, j = b - 1; i < j; ++i, --j) x.swap(i, j);
-}
-
-void pdqsort(const Data &x, long a, long b, long limit)
-{
-    const long max_insertion = 12;
-    bool was_balanced = true, was_partitioned = true;
-    for (;;) {
-        const long length = b - a;
-        if (length <= max_insertion) {
-            insertion_sort(x, a, b);
-            return;
-        }
-        if (limit == 0) {
-            heap_sort(x, a, b);
-            return;
-        }
-        if (!was_balanced) {
-            break_patterns(x, a, b);
-            --limit;
-        }
-        Hint hint;
-        long pivot = choose_pivot(x, a, b, hint);
-        if (hint == kDecreasing) {
-            reverse_range(x, a, b);
-            pivot = (b - 1) - (pivot - a);
-            hint = kIncreasing;
-        }
-        if (was_balanced && was_partitioned && hint == kIncreasing && partial_insertion_sort(x, a, b)) return;
-        if (a > 0 && !x.less(a - 1, pivot)) {
-            a = partition_equal(x, a, b, pivot);
-            continue;
-        }
-        bool already = false;
-        const long mid = partition(x, a, b, pivot, already);
-        was_partitioned = already;
-        const long left = mid - a, right = b - mid, balance = length / 8;
-        if (left < right) {
-            was_balanced = left >= balance;
-            pdqsort(x, a, mid, limit);
-            a = mid + 1;
-        } else {
-            was_balanced = right >= balance;
-            pdqsort(x, mid + 1, b, limit);
-            b = mid;
-        }
-    }
-}
-
-}  // namespace gosort
 
 extern "C" void pigo_sort_by_q(pigo_det *dets, int n)
 {

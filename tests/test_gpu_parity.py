@@ -206,9 +206,41 @@ def test_batch_api_matches_single_frame_and_is_order_stable(pg, orc):
             w = want[f].copy()
             wc, wties = orc.cluster_detections(w, 0.2, want_ties=True)
             assert int(ties[f]) == wties
-            if wties == 0:
-                assert_same_dets(cl[f], wc, f"batch clusters frame {f}", Q_TOL_RAW)
-                assert_same_dets(srt[f], w, f"batch sorted frame {f}", Q_TOL_RAW)
+            assert_same_dets(cl[f], wc, f"batch clusters frame {f}", Q_TOL_RAW)   # tie frames are re-sorted with Go's pdqsort on the GPU
+            assert_same_dets(srt[f], w, f"batch sorted frame {f}", Q_TOL_RAW)
+
+
+def test_batch_clustering_is_tie_exact(pg, orc):
+    """pigo_plan_cluster on lists with many tied Q values: the device re-sorts such frames with Go's (unstable) pdqsort, so
+    the sorted lists, the seed order and the float32 sums equal the reference's -- for lists sorted out of LDS (<= 2048)
+    and in global memory (> 2048), next to a tie-free and an empty frame."""
+    import torch
+    from pigo_amd import batch
+    cap, nfr = 4096, 5
+    plan = batch.ScanPlan(pg, 240, 320, MinSize=20, MaxSize=200, ShiftFactor=0.1, ScaleFactor=1.1, max_frames=nfr, det_cap=cap)
+    rng = np.random.default_rng(4)
+    lists = []
+    for n, levels in ((317, 40), (1500, 9), (3000, 25), (200, 10**7), (0, 3)):
+        rows = rng.integers(20, 220, n)
+        cols = rng.integers(20, 300, n)
+        scales = rng.integers(20, 90, n)
+        q = (rng.integers(1, levels + 1, n) / np.float32(3.0)).astype(np.float32)
+        lists.append(core.make_dets([(int(rows[i]), int(cols[i]), int(scales[i]), q[i]) for i in range(n)]))
+    host = np.zeros((nfr, cap), dtype=core.DET_DTYPE)
+    for f, l in enumerate(lists):
+        host[f, : len(l)] = l
+    dets = torch.from_numpy(host.view(np.int32).reshape(nfr, cap, 4)).cuda()
+    counts = torch.tensor([len(l) for l in lists], dtype=torch.int32, device="cuda")
+    sorted_, clusters, ccounts, ties = plan.cluster(dets, counts, 0.3)
+    torch.cuda.synchronize()
+    cl = batch.dets_to_numpy(clusters, ccounts)
+    srt = batch.dets_to_numpy(sorted_, counts)
+    for f, l in enumerate(lists):
+        w = _as_oracle(l)
+        wc, wties = orc.cluster_detections(w, 0.3, want_ties=True)
+        assert int(ties[f]) == wties and (wties > 0) == (f < 3)
+        assert_same_dets(srt[f], w, f"tie-exact sorted frame {f}", Q_TOL_RAW)
+        assert_same_dets(cl[f], wc, f"tie-exact clusters frame {f}", Q_TOL_RAW)
 
 
 @pytest.mark.parametrize("chunks,angle", [(2, 0.0), (3, 0.0), (1, 0.0), (0, 0.0), (2, 0.6)])
