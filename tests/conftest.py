@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_built():
+    """A fresh checkout has no libpigo_hip.so / libpigo_oracle.so (built artefacts are not in git): compile them once
+    (hipcc cross-compiles gfx950 without a GPU).  Building is not falling back: without the library every product call
+    still fails loudly."""
+    from pigo_amd import build as hip_build
+    import oracle
+    hip_build.build()
+    oracle.build()
+
+
 @pytest.fixture(scope="session")
 def packet():
     from pigo_amd import synth
