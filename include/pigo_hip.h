@@ -192,7 +192,9 @@ pigo_status pigo_plan_set_variant(pigo_plan *p, int variant);
  * Enqueues on `stream` (a hipStream_t, NULL = default stream):
  *     d_dets   [nframes][det_cap] pigo_det, reference order per frame
  *     d_counts [nframes] int32: detections found (if > det_cap the frame's list is truncated)
- * Nothing is synchronised; call pigo_plan_status() after synchronising the stream. */
+ * Nothing is synchronised; call pigo_plan_status() after synchronising the stream.  A plan owns ONE
+ * workspace: enqueue all work of a plan on the same stream (or order the streams yourself); use one
+ * plan per stream for concurrent batches. */
 pigo_status pigo_plan_run(pigo_plan *p, const uint8_t *d_frames, size_t frame_stride, int nframes, pigo_det *d_dets,
                           int32_t *d_counts, void *stream);
 
