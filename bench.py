@@ -76,8 +76,14 @@ def cpu_baseline(args, frames, windows_per_frame):
         return orc.run_cascade(f, args.rows, args.cols, args.cols, args.min_size, args.max_size, args.shift, args.scale, args.angle)
 
     t = time.perf_counter()
-    scan(frames[0])
+    d0 = scan(frames[0])
     one = time.perf_counter() - t  # also the warm-up
+    # ClusterDetections on that frame's list, timed separately (mirrors BenchmarkPigoClusterDetection, core/pigo_test.go:115-143)
+    creps = 20
+    t = time.perf_counter()
+    for _ in range(creps):
+        orc.cluster_detections(d0.copy(), args.iou)
+    cluster_ms = (time.perf_counter() - t) / creps * 1e3
     n1 = max(1, min(len(frames), int(5.0 / max(one, 1e-3))))
     t = time.perf_counter()
     for i in range(n1):
@@ -104,7 +110,7 @@ def cpu_baseline(args, frames, windows_per_frame):
                   f"(C oracle, gcc -O2; the Go reference cannot run here)",
         "frames_per_s": round(fps_all, 3),
         "single_thread": {"value": round(windows_per_frame / t1 / 1e6, 3), "unit": "Mwindows/s", "ms_per_frame": round(t1 * 1e3, 2),
-                          "frames": n1},
+                          "frames": n1, "cluster_ms_per_frame": round(cluster_ms, 4), "detections_in_that_frame": int(len(d0))},
     }
 
 
