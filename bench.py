@@ -4,9 +4,14 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+`--gpus N` with no launcher around it starts the N ranks itself (re-exec under torch.distributed.run); under a launcher
+WORLD_SIZE must equal N.
+
 One STEP = one pass of the hot path over one batch of synthetic 1080p frames that are already resident in
 HBM: RunCascade (scan + order restore) for every frame, per-frame ClusterDetections on the GPU, and -- for
-N > 1 -- one RCCL all-gather of the fixed-capacity per-frame cluster lists.  Workload = BASELINE.json
+N > 1 -- one RCCL all-gather of the fixed-capacity per-frame cluster lists, issued by libpigo_hip.so itself
+(pigo_run_batch_sharded, include/pigo_hip.h).  After the timed region the first frames of the timed batch are checked
+against the CPU oracle (`verified_frames`) and the run fails if any frame overflowed det_cap.  Workload = BASELINE.json
 configs[1] (1920x1080, facefinder, MinSize 20, MaxSize 1000, ShiftFactor 0.1, ScaleFactor 1.1) applied to a
 batch of `--frames` seeded SYN-FACES frames per GPU (weak scaling: per-GPU work is fixed as N grows).
 
@@ -60,7 +65,69 @@ def parse_args():
     ap.add_argument("--no-gray", action="store_true", help="skip the side measurements (RgbToGrayscale, RunDetector, single frame)")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call leg (keeps kernel profiles per-batch)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto, ~15 s)")
+    ap.add_argument("--verify-frames", type=int, default=8, help="frames of the timed batch checked against the CPU oracle afterwards")
+    ap.add_argument("--gather", choices=["cabi", "torch"], default="cabi",
+                    help="N > 1: all-gather through the C ABI (pigo_run_batch_sharded -> ncclAllGather) or torch.distributed")
+    ap.add_argument("--shard-frames", type=int, default=1024,
+                    help="frames of the config-3 shard leg (BASELINE configs[2]: 1024 frames per GPU); 0 = skip")
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="no GPU: fabricated lists + gloo all-gather; checks the launch / sharding / gather plumbing of --gpus N")
     return ap.parse_args()
+
+
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run and hand
+    their single JSON line through.  Under a launcher the world size must match --gpus."""
+    import socket
+    import subprocess
+    world = os.environ.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        return
+    if args.gpus <= 1:
+        return
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def cpu_dry_run(args, json_fd):
+    """The N-rank plumbing without a GPU: every rank fabricates its shard's lists, packs them into the wire format and
+    all-gathers them with gloo; rank 0 prints the record.  Not a measurement."""
+    import torch
+    import torch.distributed as dist
+    from pigo_amd import core, distributed
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, gcap = args.frames, min(args.gather_cap, args.det_cap)
+    counts = np.array([(rank * B + f) % (gcap + 2) for f in range(B)], dtype=np.int32)
+    dets = np.zeros((B, args.det_cap), dtype=core.DET_DTYPE)
+    for f in range(B):
+        dets[f, :min(counts[f], args.det_cap)]["row"] = rank * B + f
+    out = None
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        wire = torch.from_numpy(distributed.pack_lists_host(dets, counts, B, gcap))
+        out = torch.empty((world * B, wire.shape[1]), dtype=torch.int32)
+        dist.all_gather_into_tensor(out, wire)
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    seen = [None] * world
+    dist.all_gather_object(seen, rank)
+    ok = all(int(out[r * B + f, 0]) == (r * B + f) % (gcap + 2) for r in range(world) for f in range(B))
+    if rank == 0:
+        os.write(json_fd, (json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "Mwindows/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(elapsed / (args.warmup + args.steps) * 1e3, 4), "dry_run": True,
+                          "ranks_seen": sorted(seen), "gathered_rows": int(out.shape[0]), "gather_ok": bool(ok)}) + "\n").encode())
+    dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
 
 
 def cpu_baseline(args, frames, windows_per_frame):
@@ -114,13 +181,52 @@ def cpu_baseline(args, frames, windows_per_frame):
     }
 
 
+def verify_against_oracle(args, frames, dets, counts, clusters, ccounts, k):
+    """Bit-exact check of the first k frames of the timed batch (raw RunCascade lists and clusters) against the CPU oracle,
+    one host thread per frame.  Raises on any difference: a fast wrong answer must not produce a bench line."""
+    import threading
+    import oracle
+    from pigo_amd import batch, synth
+    orc = oracle.OraclePigo.unpack(synth.facefinder_bytes())
+    got = batch.dets_to_numpy(dets[:k], counts[:k])
+    gcl = batch.dets_to_numpy(clusters[:k], ccounts[:k]) if clusters is not None else None
+    want, wantc = [None] * k, [None] * k
+
+    def work(f):
+        want[f] = orc.run_cascade(frames[f], args.rows, args.cols, args.cols, args.min_size, args.max_size, args.shift, args.scale, args.angle)
+        wantc[f] = orc.cluster_detections(want[f].copy(), args.iou)
+
+    th = [threading.Thread(target=work, args=(f,)) for f in range(k)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+
+    def same(a, b, what):
+        if len(a) != len(b):
+            raise SystemExit(f"bench.py: VERIFICATION FAILED: {what}: {len(a)} records, oracle {len(b)}")
+        for i in range(len(a)):
+            if (int(a[i]["row"]), int(a[i]["col"]), int(a[i]["scale"])) != (int(b[i]["row"]), int(b[i]["col"]), int(b[i]["scale"])) or \
+                    np.float32(a[i]["q"]) != np.float32(b[i]["q"]):
+                raise SystemExit(f"bench.py: VERIFICATION FAILED: {what} record {i}: {a[i]} vs oracle {b[i]}")
+
+    for f in range(k):
+        same(got[f], want[f], f"frame {f} RunCascade")
+        if gcl is not None:
+            same(gcl[f], wantc[f], f"frame {f} ClusterDetections")
+    return k
+
+
 def main():
     args = parse_args()
-    # stdout carries exactly ONE line, the JSON record: native libraries (RCCL prints its version banner to stdout) and
+    spawn_ranks_if_needed(args)
+    # stdout carries exactly ONE line, the JSON record: native libraries (RCCL and gloo print banners to stdout) and
     # anything else that writes to fd 1 go to stderr for the duration of the run
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.cpu_dry_run:
+        return cpu_dry_run(args, json_fd)
     import torch
     import torch.distributed as dist
     from pigo_amd import batch, core, distributed, synth
@@ -133,8 +239,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     n_gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -153,7 +257,27 @@ def main():
     gcap = min(args.gather_cap, args.det_cap)
     cl_out = plan.alloc_cluster_outputs(dets, counts)
 
+    # N > 1: the all-gather belongs to the step.  Default: the C ABI's own RCCL communicator (what a Go / C++ host would
+    # use); torch.distributed only ships the 128-byte RCCL id.  If that communicator cannot be created the run says so
+    # on stderr and in the record and uses torch.distributed's all-gather (RCCL as well) instead.
+    comm, gather_mode, gathered = None, None, None
+    if use_dist:
+        gather_mode = args.gather
+        if gather_mode == "cabi":
+            try:
+                comm = distributed.Comm.from_torch(local_rank)
+            except Exception as e:  # noqa: BLE001 -- reported, not swallowed
+                print(f"[rank {rank}] pigo_comm_init failed ({e}); using torch.distributed for the all-gather", file=sys.stderr)
+                comm = None
+            flag = torch.tensor([1 if comm is not None else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                comm, gather_mode = None, "torch (pigo_comm_init failed)"
+        gathered = torch.zeros((world * B, 1 + 4 * gcap), dtype=torch.int32, device=dev)
+
     def step():
+        if comm is not None:  # scan + cluster + pack + ncclAllGather, all enqueued by libpigo_hip.so
+            return distributed.run_batch_sharded(plan, comm, d_frames, B, -1.0 if args.no_cluster else args.iou, gcap, out=gathered)
         plan.run(d_frames, dets, counts)
         if args.no_cluster:
             lists, lcounts = dets, counts
@@ -178,7 +302,37 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    plan.status()
+    last = step() if use_dist else None  # (untimed) one more gathered result for the checks below
+    torch.cuda.synchronize()
+    plan.status()   # queue overflow, would-panic frame or a frame with more than det_cap detections: no bench line
+    if comm is not None:  # the sharded entry point keeps its lists inside the plan: run the plain path once for the checks
+        plan.run(d_frames, dets, counts)
+        if not args.no_cluster:
+            plan.cluster(dets, counts, args.iou, out=cl_out)
+        torch.cuda.synchronize()
+        plan.status()
+    if int(counts.max().item()) > args.det_cap:
+        raise SystemExit(f"bench.py: a frame has {int(counts.max().item())} detections, det_cap is {args.det_cap}: truncated lists")
+    verified = 0
+    if rank == 0 and args.verify_frames > 0:
+        verified = verify_against_oracle(args, frames, dets, counts, None if args.no_cluster else cl_out[1],
+                                         None if args.no_cluster else cl_out[2], min(args.verify_frames, B))
+        if last is not None:  # rank 0's own rows of the gathered tensor are its cluster lists in wire format
+            ref = distributed.pack_lists(dets if args.no_cluster else cl_out[1], counts if args.no_cluster else cl_out[2], gcap)
+            if not torch.equal(last[:B], ref):
+                raise SystemExit("bench.py: VERIFICATION FAILED: gathered rows of rank 0 differ from its lists")
+            if world > 1:  # ... and a frame scanned by ANOTHER rank, as it arrived through the all-gather, against the oracle
+                import oracle
+                fo = synth.make_frames(args.kind, 1, args.rows, args.cols, seed=args.seed, first_index=(world - 1) * B)[0]
+                orc = oracle.OraclePigo.unpack(synth.facefinder_bytes())
+                w = orc.run_cascade(fo, args.rows, args.cols, args.cols, args.min_size, args.max_size, args.shift, args.scale, args.angle)
+                if not args.no_cluster:
+                    w = orc.cluster_detections(w.copy(), args.iou)
+                g, cnt = distributed.unpack_list_host(last[(world - 1) * B].cpu().numpy(), gcap)
+                if cnt != len(w) or any((int(a["row"]), int(a["col"]), int(a["scale"]), np.float32(a["q"])) !=
+                                        (int(b["row"]), int(b["col"]), int(b["scale"]), np.float32(b["q"])) for a, b in zip(g, w[:gcap])):
+                    raise SystemExit(f"bench.py: VERIFICATION FAILED: frame {(world - 1) * B} (rank {world - 1}) through the all-gather")
+                verified += 1
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -216,7 +370,8 @@ def main():
     # ---- BASELINE configs[1] as stated: ONE 1080p frame.  (a) resident in HBM, back-to-back launches of the plan;
     # (b) RunCascade on a host buffer: H2D of the frame, scan, D2H of the detections (PCIe-inclusive; never `value`)
     single_leg = None
-    if rank == 0 and not args.no_gray and not args.no_single_frame:
+    side_legs = rank == 0 and n_gpus == 1 and not args.no_gray
+    if side_legs and not args.no_single_frame:
         plan1 = batch.ScanPlan(pg, args.rows, args.cols, MinSize=args.min_size, MaxSize=args.max_size, ShiftFactor=args.shift,
                                ScaleFactor=args.scale, angle=args.angle, max_frames=1, det_cap=args.det_cap)
         d1, c1 = plan1.alloc_outputs(1)
@@ -246,7 +401,7 @@ def main():
     # ---- side measurement, outside the timed region: RgbToGrayscale (core/grayscale.go:8-23), the streaming step in
     # front of the scan.  RGBA frames {g,g,g,255} built on the GPU from the gray batch; the kernel must give them back.
     gray_leg = None
-    if rank == 0 and not args.no_gray:
+    if side_legs:
         gn = min(B, 64)
         rgba = torch.empty((gn, args.rows, args.cols, 4), dtype=torch.uint8, device=dev)
         rgba[..., :3] = d_frames[:gn].unsqueeze(-1)
@@ -271,7 +426,7 @@ def main():
     # ---- side measurement: RunDetector (core/puploc.go:239-277), the step behind ClusterDetections.  4096 eye-sized
     # requests with 63 perturbations each, spread over the resident frames; one launch, one workgroup per request.
     pup_leg = None
-    if rank == 0 and not args.no_gray:
+    if side_legs:
         plc = core.NewPuplocCascade(local_rank).UnpackCascade(synth.cascade_bytes("puploc"))
         nreq = 4096
         rng = np.random.default_rng(args.seed)
@@ -295,8 +450,16 @@ def main():
         torch.cuda.synchronize()
         batch.puploc_status(plc)
         pms = pev[0].elapsed_time(pev[1]) / preps
+        # bound: every level of every tree walk is one dependent round trip to L2 (codes + two pixels); nothing streams.
+        # Algorithmic bytes per request: 63 perturbations x 100 trees x 10 levels x (4 B code + 2 B pixels) + 100 x 63 x 8 B
+        # leaves = 428 KB of cache-line-granular gathers out of a 1.2 MB table, i.e. latency, not bandwidth
+        pbytes = nreq * (63 * 100 * 10 * 6 + 63 * 100 * 8)
         pup_leg = {"kernel": "k_puploc", "requests": nreq, "perturbs": 63, "ms_per_launch": round(pms, 4),
-                   "requests_per_s": round(nreq / (pms * 1e-3), 1), "tree_walks_per_s": round(nreq * 63 * 100 / (pms * 1e-3), 1)}
+                   "requests_per_s": round(nreq / (pms * 1e-3), 1), "tree_walks_per_s": round(nreq * 63 * 100 / (pms * 1e-3), 1),
+                   "bound": "latency (dependent L2 gathers: 10 levels x 100 trees per perturbation, one round trip per level)",
+                   "gather_bytes_per_launch": pbytes, "gather_gbs": round(pbytes / (pms * 1e-3) / 1e9, 1),
+                   "dependent_round_trips_per_request": 5 * 10, "note": "5 stages x 10 levels are serial per perturbation; "
+                   "63 perturbations x 20 trees of a stage run in parallel lanes"}
         if not args.no_cpu_baseline:
             import oracle
             oplc = oracle.OraclePuploc.unpack(synth.cascade_bytes("puploc"))
@@ -306,6 +469,36 @@ def main():
                 oplc.run_detector(int(r["row"]), int(r["col"]), float(r["scale"]), 63, frames[r["frame"]], args.rows, args.cols, args.cols, 0.0,
                                   False, rnd[i], None)
             pup_leg["cpu_requests_per_s_one_thread"] = round(40 / (time.perf_counter() - t), 1)
+
+    # ---- BASELINE configs[2]'s per-GPU shard: 1024 resident frames (2.1 GB) per step; same plan parameters, seeded frames
+    shard_leg = None
+    if side_legs and args.shard_frames > B and (args.rows, args.cols) == (1080, 1920):
+        S = args.shard_frames
+        fS = synth.make_frames(args.kind, S, args.rows, args.cols, seed=args.seed, first_index=0)
+        dS = torch.from_numpy(fS).to(dev)
+        planS = batch.ScanPlan(pg, args.rows, args.cols, MinSize=args.min_size, MaxSize=args.max_size, ShiftFactor=args.shift,
+                               ScaleFactor=args.scale, angle=args.angle, max_frames=S, det_cap=args.det_cap)
+        detS, cntS = planS.alloc_outputs(S)
+        clS = planS.alloc_cluster_outputs(detS, cntS)
+
+        def stepS():
+            planS.run(dS, detS, cntS)
+            planS.cluster(detS, cntS, args.iou, out=clS)
+
+        stepS()
+        torch.cuda.synchronize()
+        tS = time.perf_counter()
+        for _ in range(3):
+            stepS()
+        torch.cuda.synchronize()
+        msS = (time.perf_counter() - tS) / 3 * 1e3
+        planS.status()
+        assert int(cntS.max().item()) <= args.det_cap
+        assert torch.equal(cntS[:B], counts) and torch.equal(detS[:B], dets), "the shard's first frames must reproduce the default batch"
+        shard_leg = {"frames_per_gpu": S, "ms_per_step": round(msS, 3), "mwindows_per_s": round(S * int(info.windows_per_frame) / msS / 1e3, 1),
+                     "frames_per_s": round(S / msS * 1e3, 1), "resident_bytes": int(fS.nbytes), "detections": int(cntS.sum().item()),
+                     "note": "BASELINE configs[2] per-GPU shard (8192 frames / 8 GPUs); first frames compared with the default batch"}
+        del planS, dS, detS, cntS, clS, fS
 
     if rank == 0:
         wpf = int(info.windows_per_frame)
@@ -343,8 +536,15 @@ def main():
                 "frames_per_gpu": B, "windows_per_frame": wpf, "scales": int(info.n_scales), "variant": int(info.variant),
                 "head_trees": int(info.n_head_trees), "detections_per_batch": ndet,
                 "head_survivor_fraction": round(survivors / (B * wpf), 5) if wpf else None,
-                "parallelism": f"frames sharded over {n_gpus} GPU(s), no data-path collective during the scan",
+                "parallelism": f"frames sharded over {n_gpus} GPU(s), no data-path collective during the scan"
+                               + (f"; one all-gather per step via {gather_mode}" if use_dist else ""),
             },
+            "verified_frames": verified,
+            "verification": "first frames of the timed batch vs the CPU oracle, raw lists and clusters bit-exact (q 0 ulp); counts.max() <= det_cap"
+                            + ("; rank 0's gathered rows vs its lists; one frame of the last rank through the all-gather" if use_dist else ""),
+            "gather": gather_mode,
+            "kernel_ms_schedule": "per-kernel HIP-event times are taken with the chunked pipeline and the side stream OFF (each launch alone on "
+                                  "the stream, as rocprofv3 sees them); the timed step overlaps them, so ms_per_step can be below their sum",
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items() if k != "end"},
             "cluster_ms": round(cluster_ms, 4) if cluster_ms is not None else None,
             "roofline": {
@@ -357,6 +557,7 @@ def main():
                 "note": "compulsory bytes only (each frame read once); the kernel is gather/issue bound, see DESIGN.md",
             },
         }
+        out["config3_shard"] = shard_leg
         out["single_frame"] = single_leg
         out["gray"] = gray_leg
         out["puploc"] = pup_leg

@@ -180,8 +180,9 @@ typedef struct {
 pigo_status pigo_plan_info(const pigo_plan *p, pigo_plan_info_t *info);
 
 /* Selects the scan implementation for this plan:
- *   0 = monolithic lane-per-window kernel (any tree depth; also variant 1's overflow fallback),
- *   1 = dense head kernel + survivor queue + tail kernel, pixels gathered from global memory,
+ *   0 = monolithic lane-per-window kernel (any tree depth; also the overflow fallback),
+ *   1 = the first design (dense head kernel + survivor queue + tail kernel, pixels gathered from global memory); it is
+ *       compiled into the debug build only (python -m pigo_amd.build --debug) -- PIGO_ERR_PARAM in the release library,
  *   2 = one workgroup takes a tile of windows through the whole cascade out of an LDS copy of the tile's
  *       pixels (default when the cascade has depth 6). */
 pigo_status pigo_plan_set_variant(pigo_plan *p, int variant);
@@ -208,8 +209,11 @@ pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, const int32_
                               pigo_det *d_sorted, pigo_det *d_clusters, int32_t *d_ccounts, int32_t *d_ties, void *stream);
 
 /* After the stream has been synchronised: PIGO_OK, PIGO_ERR_PANIC (the reference would have
- * panicked on some frame) or PIGO_ERR_CAPACITY (survivor queue overflowed: results of the last run
- * are incomplete; pigo_plan_run_sync handles this by re-running with the monolithic kernel). */
+ * panicked on some frame) or PIGO_ERR_CAPACITY -- either the survivor queue overflowed (results of
+ * the last run are incomplete; pigo_plan_run_sync handles this by re-running with the monolithic
+ * kernel) or some frame has more than det_cap detections (its list is truncated, and which records
+ * were kept is not deterministic; d_counts holds the true count: re-plan with a larger det_cap).
+ * pigo_last_error() says which. */
 pigo_status pigo_plan_status(pigo_plan *p);
 
 /* Synchronous convenience wrapper: run + synchronise + overflow fallback. */
@@ -221,7 +225,8 @@ pigo_status pigo_plan_run_sync(pigo_plan *p, const uint8_t *d_frames, size_t fra
 pigo_status pigo_plan_set_profiling(pigo_plan *p, int on);
 int pigo_plan_last_timings(pigo_plan *p, const char **names, float *ms, int cap);
 
-/* Debug only (plans created with PIGO_DEBUG_STATS=1 in the environment): accumulated shader-clock totals of
+/* Debug build only (libpigo_hip_debug.so, plans created with PIGO_DEBUG_STATS=1 in the environment; the release
+ * library carries no instrumentation in its kernels and returns zeros): accumulated shader-clock totals of
  * k_scan_tile's phases since the last call -- [0] tile/table copies, [1] stage 0, [2] later dense stages,
  * [3] late mode, [4] tiles, [5] windows entering late mode, [6] trees walked in late mode.  Zeros otherwise. */
 pigo_status pigo_plan_debug_stats(pigo_plan *p, uint64_t *out, int n);
@@ -232,6 +237,41 @@ pigo_status pigo_plan_debug_trace(pigo_plan *p, uint64_t *out, int n);
  * frames are pipelined in chunks over two queue sets; the figure then covers the last chunk that used the first set
  * (bench.py reads it after an un-pipelined profiling run). */
 pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n);
+
+/* ---- multi-GPU batch: frames sharded over ranks + ONE RCCL all-gather (BASELINE config 3; no reference counterpart) ----
+ * RunCascade is a single goroutine over one image (core/pigo.go:212-258) and frames are independent, so a batch is cut into
+ * contiguous shards, one process per GPU, with no exchange during the scan; the per-frame lists are exchanged once at the
+ * end.  RCCL has no all-gather-v: every frame travels as one fixed-size row of pigo_wire_words(gather_cap) = 1 + 4*gather_cap
+ * int32 -- the TRUE count (count > gather_cap marks a truncated row), then the first min(count, gather_cap) pigo_det records,
+ * zero-padded.  librccl is bound with dlopen at first use (PIGO_RCCL_LIB overrides the name).
+ *
+ *   rank 0:      pigo_comm_unique_id(id)            -- ncclGetUniqueId; the host program ships the 128 bytes to every rank
+ *   every rank:  pigo_comm_init(id, rank, world, device, &comm)   -- ncclCommInitRank (collective)
+ *                pigo_shard_bounds(nframes, rank, world, &lo, &hi)
+ *                pigo_run_batch_sharded(plan, comm, d_frames + lo*stride, stride, hi - lo, frames_per_rank, iou, gather_cap,
+ *                                       d_gathered, stream)
+ * world == 1 needs no RCCL at all (id may be NULL). */
+typedef struct pigo_comm pigo_comm;
+#define PIGO_COMM_ID_BYTES 128
+pigo_status pigo_comm_unique_id(uint8_t id[PIGO_COMM_ID_BYTES]);
+pigo_status pigo_comm_init(const uint8_t id[PIGO_COMM_ID_BYTES], int rank, int world, int device, pigo_comm **out);
+pigo_status pigo_comm_info(const pigo_comm *c, int *rank, int *world);
+void pigo_comm_destroy(pigo_comm *c);
+/* contiguous shard [lo, hi) of `nframes` frames for `rank`; earlier ranks take the remainder */
+void pigo_shard_bounds(int nframes, int rank, int world, int *lo, int *hi);
+size_t pigo_wire_words(int gather_cap);
+/* Scan (+ per-frame ClusterDetections when iou_threshold >= 0; a negative or NaN threshold gathers the raw RunCascade lists)
+ * this rank's `nframes_local` device-resident frames and all-gather the wire rows of all ranks:
+ *     d_gathered [world * frames_per_rank][pigo_wire_words(gather_cap)] int32, device memory; rank r's frames are rows
+ *     [r*frames_per_rank, r*frames_per_rank + its nframes_local), the rest of its rows are zero-count padding.
+ * Everything is enqueued on `stream`; the collective is the last operation.  Every rank of the communicator must call
+ * with the same frames_per_rank and gather_cap.  pigo_plan_status() applies as for pigo_plan_run. */
+pigo_status pigo_run_batch_sharded(pigo_plan *p, pigo_comm *comm, const uint8_t *d_frames, size_t frame_stride, int nframes_local,
+                                   int frames_per_rank, double iou_threshold, int gather_cap, int32_t *d_gathered, void *stream);
+/* The wire format on the host (what pigo_run_batch_sharded packs on the device): rows [nframes, frames_out) are padding. */
+pigo_status pigo_pack_lists(const pigo_det *lists, const int32_t *counts, int nframes, int frames_out, int cap, int gather_cap,
+                            int32_t *wire);
+pigo_status pigo_unpack_list(const int32_t *wire_row, int gather_cap, pigo_det *out, int cap, int *n_out, int *true_count);
 
 #ifdef __cplusplus
 }

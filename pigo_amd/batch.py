@@ -149,16 +149,19 @@ def rgb_to_grayscale(rgba, kind=core.PIX_NRGBA, out=None, dim=None, stream=None)
     return out
 
 
-def puploc_run_batch(plc: "core.PuplocCascade", frames, reqs, rnd, angle=0.0, pool=None, out=None, stream=None):
+def puploc_run_batch(plc: "core.PuplocCascade", frames, reqs, rnd, angle=0.0, pool=None, out=None, stream=None, cols=None):
     """n independent RunDetector calls (core/puploc.go:239-277) against device-resident gray frames, one launch.
 
-    frames: uint8 [f, rows, dim] on the GPU; reqs: uint8/int32 tensor holding n ``core.PUPLOC_REQ_DTYPE`` records
+    frames: uint8 [f, rows, dim] on the GPU, of which the first `cols` (default dim) columns of every row are image --
+    ImageParams.Cols, what the reference clamps column indices with (puploc.go:118-128); reqs: uint8/int32 tensor holding n ``core.PUPLOC_REQ_DTYPE`` records
     (24 B each: row, col, scale, perturbs, frame, flip_v); rnd: float32 [n, 189] perturbation randoms in draw order;
     pool: float32 [n, 189] in/out or None (fresh pool objects).  Returns an int32 [n, 4] tensor of ``core.PUPLOC_DTYPE``
     records (row, col, scale-bits, 0).  Call ``puploc_status(plc)`` after synchronising."""
     torch = _torch()
     assert frames.dtype == torch.uint8 and frames.is_cuda and frames.is_contiguous() and frames.dim() == 3
     nf, rows, dim = (int(v) for v in frames.shape)
+    cols = dim if cols is None else int(cols)
+    assert 1 <= cols <= dim, (cols, dim)
     assert reqs.is_cuda and reqs.is_contiguous() and reqs.numel() * reqs.element_size() % 24 == 0
     n = reqs.numel() * reqs.element_size() // 24
     assert rnd.dtype == torch.float32 and rnd.is_cuda and rnd.is_contiguous() and tuple(rnd.shape) == (n, 3 * core.POOL_SIZE), rnd.shape
@@ -167,7 +170,7 @@ def puploc_run_batch(plc: "core.PuplocCascade", frames, reqs, rnd, angle=0.0, po
     if out is None:
         out = torch.zeros((n, 4), dtype=torch.int32, device=frames.device)
     L = core.load_library()
-    core.check(L.pigo_puploc_run_batch(plc._need(), C.c_void_p(frames.data_ptr()), rows * dim, nf, rows, dim, dim, float(angle),
+    core.check(L.pigo_puploc_run_batch(plc._need(), C.c_void_p(frames.data_ptr()), rows * dim, nf, rows, cols, dim, float(angle),
                                        C.c_void_p(reqs.data_ptr()), C.c_void_p(rnd.data_ptr()),
                                        C.c_void_p(pool.data_ptr()) if pool is not None else None, n, C.c_void_p(out.data_ptr()),
                                        ScanPlan._stream_ptr(stream)), "puploc_run_batch")

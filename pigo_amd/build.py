@@ -10,6 +10,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libpigo_hip.so")
+#: debug build (-DPIGO_DEBUG_BUILD): phase timers inside the scan kernels (PIGO_DEBUG_STATS=1) and the superseded variant-1
+#: kernels; never loaded unless PIGO_HIP_LIB points at it (scripts/ A/B runs)
+LIB_DEBUG = os.path.join(CSRC, "libpigo_hip_debug.so")
 SOURCES = [os.path.join(CSRC, "pigo_hip.hip")]
 DEPS = SOURCES + [os.path.join(CSRC, "pigo_kernels.hip.inc"), os.path.join(HERE, "..", "include", "pigo_hip.h")]
 
@@ -25,23 +28,27 @@ def hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm): libpigo_hip.so cannot be built")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    """Compile libpigo_hip.so if it is missing or older than its sources.  Returns the path."""
-    if force or needs_build():
-        cmd = [hipcc()] + HIPCC_FLAGS + SOURCES + ["-o", LIB + ".tmp"]
+def build(force=False, verbose=False, debug=False, defines=(), out=None):
+    """Compile libpigo_hip.so (or, with debug=True, libpigo_hip_debug.so) if it is missing or older than its sources.
+    `defines` / `out` build experimental variants next to it (scripts/ A/B runs).  Returns the path."""
+    lib = out or (LIB_DEBUG if debug else LIB)
+    if force or needs_build(lib):
+        flags = list(HIPCC_FLAGS) + (["-DPIGO_DEBUG_BUILD"] if debug else []) + ["-D" + d for d in defines]
+        cmd = [hipcc()] + flags + SOURCES + ["-o", lib + ".tmp"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)
-        os.replace(LIB + ".tmp", LIB)
-    return LIB
+        os.replace(lib + ".tmp", lib)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, debug="--debug" in sys.argv[1:]))

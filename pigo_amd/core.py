@@ -53,6 +53,8 @@ ABI_SYMBOLS = [
     "pigo_rgb_to_grayscale", "pigo_gray_batch",
     "pigo_puploc_create", "pigo_puploc_info", "pigo_puploc_destroy", "pigo_puploc_run_detector", "pigo_get_landmark_point",
     "pigo_puploc_run_batch", "pigo_puploc_status",
+    "pigo_comm_unique_id", "pigo_comm_init", "pigo_comm_info", "pigo_comm_destroy", "pigo_shard_bounds", "pigo_wire_words",
+    "pigo_run_batch_sharded", "pigo_pack_lists", "pigo_unpack_list",
 ]
 
 _lib = None
@@ -134,9 +136,21 @@ def load_library():
     L.pigo_get_landmark_point.argtypes = [vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, vp, vp, vp]
     L.pigo_puploc_run_batch.argtypes = [vp, vp, sz, i32, i32, i32, i32, dbl, vp, vp, vp, i32, vp, vp]
     L.pigo_puploc_status.argtypes = [vp]
+    L.pigo_comm_unique_id.argtypes = [vp]
+    L.pigo_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.pigo_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.pigo_comm_destroy.argtypes = [vp]
+    L.pigo_comm_destroy.restype = None
+    L.pigo_shard_bounds.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.pigo_shard_bounds.restype = None
+    L.pigo_wire_words.argtypes = [i32]
+    L.pigo_wire_words.restype = sz
+    L.pigo_run_batch_sharded.argtypes = [vp, vp, vp, sz, i32, i32, dbl, i32, vp, vp]
+    L.pigo_pack_lists.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    L.pigo_unpack_list.argtypes = [vp, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("pigo_device_count", "pigo_plan_last_timings"):
+        if fn.restype is C.c_int and name not in ("pigo_device_count", "pigo_plan_last_timings", "pigo_wire_words"):
             fn.restype = C.c_int
     _lib = L
     return L

@@ -158,6 +158,9 @@ struct pigo_plan {
     DevBuf<int32_t> d_flags;
     DevBuf<float> d_mq;
     DevBuf<unsigned long long> d_stats;
+    // pigo_run_batch_sharded: this rank's lists and the wire rows it contributes to the all-gather
+    DevBuf<pigo_det> sh_dets, sh_sorted, sh_clusters;
+    DevBuf<int32_t> sh_counts, sh_wire;
     long long qcap = 0;
     // profiling
     bool profiling = false;
@@ -165,6 +168,7 @@ struct pigo_plan {
     std::vector<const char *> ev_names;
     int n_timed = 0;
     int last_nframes = 0;
+    int32_t last_flags[3] = {0, 0, 0};   // what the most recent pigo_plan_status read: queue overflow, panic, det_cap overflow
     std::mutex mu;
     // the global-gather tile classes (vector-memory bound) run on a side stream next to the LDS-tile classes (LDS bound)
     hipStream_t side = nullptr;
@@ -350,7 +354,8 @@ pigo_status build_ladder(pigo_plan &p)
     return PIGO_OK;
 }
 
-// Compaction points of the cascade: trees whose threshold is a real one (facefinder: 24 of 468; the rest
+#ifdef PIGO_DEBUG_BUILD
+// (variant 1) Compaction points of the cascade: trees whose threshold is a real one (facefinder: 24 of 468; the rest
 // hold the -15 sentinel and never reject).  Correctness does not depend on this choice -- every tree's
 // threshold is tested at every tree -- it only decides where survivors are re-packed.
 void build_stages(pigo_plan &p, int head_stages_wanted)
@@ -389,6 +394,7 @@ void build_stages(pigo_plan &p, int head_stages_wanted)
         for (int v : tail) a.tail_end[a.n_tail_stages++] = v;
     }
 }
+#endif  // PIGO_DEBUG_BUILD
 
 int env_int(const char *name, int dflt);
 
@@ -589,7 +595,7 @@ pigo_status plan_alloc_batch(pigo_plan &p, int max_frames, int det_cap)
     p.det_cap = det_cap;
     // survivor queue: room for 1/8 of a frame's windows (noise keeps 5.5 % after four trees); an overflow
     // is detected on the device and answered with the monolithic kernel (pigo_plan_run_sync).
-    long long qcap = std::max<long long>(4096, p.windows / env_int("PIGO_QUEUE_DIV", 8));
+    long long qcap = std::max<long long>(std::max(8, env_int("PIGO_QUEUE_MIN", 4096)), p.windows / env_int("PIGO_QUEUE_DIV", 8));
     qcap = std::min<long long>(qcap, std::max<long long>(p.windows, 1));
     qcap = (qcap + kTailChunk - 1) / kTailChunk * kTailChunk;
     p.qcap = qcap;
@@ -710,12 +716,14 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.codes = c->d_codes.p;
     a.late_waves = std::max(1, std::min(kLateWaves, env_int("PIGO_LATE_WAVES", kLateWaves)));
     a.qb_div = 2;  // per class, see build_tile_classes
+#ifdef PIGO_DEBUG_BUILD
     a.stats = nullptr;
     if (env_int("PIGO_DEBUG_STATS", 0)) {
         HIP_TRY(p->d_stats.alloc(65536 * 8 + 16 * 256 + 256 * 8));
         HIP_TRY(hipMemset(p->d_stats.p, 0, (65536 * 8 + 16 * 256 + 256 * 8) * 8));
         a.stats = p->d_stats.p;
     }
+#endif
     a.qcos = kQCos[p->angle_idx];
     a.qsin = kQSin[p->angle_idx];
     a.leaf = c->d_leaf.p;
@@ -733,9 +741,16 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.depth = (int)c->depth;
     a.qcap = (uint32_t)p->qcap;
     a.det_cap = det_cap;
+    // variant 2 (LDS tiles, whole cascade per tile) for depth-6 cascades, variant 0 (monolithic lane-per-window kernel) for
+    // everything else and as the overflow answer; variant 1 (the first head + tail design) exists in the debug build only
+    p->variant = (c->depth == 6 && c->ntrees > 0 && p->tile_ok) ? env_int("PIGO_SCAN_VARIANT", 2) : 0;
+    if (p->variant == 2 && !p->tile_ok) p->variant = 0;
+#ifdef PIGO_DEBUG_BUILD
     build_stages(*p, env_int("PIGO_HEAD_STAGES", kMaxHeadStages));
-    p->variant = (c->depth == 6 && c->ntrees > 0) ? env_int("PIGO_SCAN_VARIANT", p->tile_ok ? 2 : 1) : 0;
-    if (p->variant == 2 && !p->tile_ok) p->variant = 1;
+    if (p->variant == 1 && !(c->depth == 6 && c->ntrees > 0)) p->variant = 0;
+#else
+    if (p->variant == 1) p->variant = 0;
+#endif
     if (p->variant < 0 || p->variant > 2) p->variant = 0;
     out = std::move(p);
     return PIGO_OK;
@@ -881,6 +896,7 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             for (int set = 0; set < 2; ++set)
                 if (used[set]) (void)hipStreamWaitEvent(s, p.ev_tail[set], 0);
         }
+#ifdef PIGO_DEBUG_BUILD
     } else if (variant == 1) {
         mark("scan_head");
         k_scan_head<ROT, GUARD><<<nb, kThreads, 0, s>>>(a);
@@ -888,6 +904,7 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             mark("scan_tail");
             k_scan_tail<ROT, GUARD><<<(uint32_t)a.nframes * (uint32_t)a.tail_wgs, kThreads, 0, s>>>(a);
         }
+#endif
     } else {
         mark("scan_mono");
         k_scan_mono<ROT, GUARD><<<nb, kThreads, 0, s>>>(a);
@@ -993,6 +1010,9 @@ extern "C" pigo_status pigo_plan_set_variant(pigo_plan *p, int variant)
 {
     if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
     if (variant < 0 || variant > 2) return fail(PIGO_ERR_PARAM, "variant must be 0, 1 or 2");
+#ifndef PIGO_DEBUG_BUILD
+    if (variant == 1) return fail(PIGO_ERR_PARAM, "variant 1 exists in the debug build only (python -m pigo_amd.build --debug)");
+#endif
     if (variant >= 1 && !(p->c->depth == 6 && p->c->ntrees > 0)) return fail(PIGO_ERR_PARAM, "variants 1 and 2 need a depth-6 cascade");
     if (variant == 2 && !p->tile_ok) return fail(PIGO_ERR_PARAM, "variant 2 not available for this cascade");
     p->variant = variant;
@@ -1013,9 +1033,13 @@ extern "C" pigo_status pigo_plan_status(pigo_plan *p)
     HIP_TRY(hipSetDevice(p->c->device));
     int32_t flags[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(flags, p->d_flags.p, 16, hipMemcpyDeviceToHost));
-    if (flags[0] || flags[1]) HIP_TRY(hipMemset(p->d_flags.p, 0, 16));
+    if (flags[0] || flags[1] || flags[2]) HIP_TRY(hipMemset(p->d_flags.p, 0, 16));
+    p->last_flags[0] = flags[0];
+    p->last_flags[1] = flags[1];
+    p->last_flags[2] = flags[2];
     if (flags[1]) return fail(PIGO_ERR_PANIC, "the reference would panic: pixel index out of range in classifyRotatedRegion (pigo.go:167-179)");
     if (flags[0]) return fail(PIGO_ERR_CAPACITY, "survivor queue overflow");
+    if (flags[2]) return fail(PIGO_ERR_CAPACITY, "a frame has more than det_cap (%d) detections: its list is truncated (d_counts holds the true count)", p->det_cap);
     return PIGO_OK;
 }
 
@@ -1029,7 +1053,7 @@ extern "C" pigo_status pigo_plan_run_sync(pigo_plan *p, const uint8_t *d_frames,
     if (st != PIGO_OK) return st;
     HIP_TRY(hipStreamSynchronize(s));
     st = pigo_plan_status(p);
-    if (st == PIGO_ERR_CAPACITY && p->variant >= 1) {  // pathological frame: more survivors than the queue holds
+    if (st == PIGO_ERR_CAPACITY && p->last_flags[0] && p->variant >= 1) {  // pathological frame: more survivors than the queue holds
         st = plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, s, 0);
         if (st != PIGO_OK) return st;
         HIP_TRY(hipStreamSynchronize(s));
@@ -1217,6 +1241,7 @@ extern "C" pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, 
         if (c->d_small.n < 4) HIP_TRY(c->d_small.alloc(4));
         HIP_TRY(hipMemcpy(c->d_frame.p, pixels, fbytes, hipMemcpyHostToDevice));
         pigo_status st = pigo_plan_run_sync(p, c->d_frame.p, fbytes, 1, c->d_dets.p, c->d_small.p, nullptr);
+        if (st == PIGO_ERR_CAPACITY && p->last_flags[2] && !p->last_flags[0]) st = PIGO_OK;  // det_cap overflow: grown below
         if (st != PIGO_OK) return st;
         int32_t n = 0;
         HIP_TRY(hipMemcpy(&n, c->d_small.p, 4, hipMemcpyDeviceToHost));
@@ -1514,4 +1539,226 @@ extern "C" pigo_status pigo_get_landmark_point(pigo_puploc_cascade *c, const pig
     flploc.scale = (float)scale;
     flploc.perturbs = perturb;
     return pigo_puploc_run_detector(c, &flploc, pixels, npixels, rows, cols, dim, 0.0, flip_v, rnd, pool, out);  // flploc.go:53-56
+}
+
+// ---- multi-GPU: frames sharded over ranks, one RCCL all-gather of the per-frame lists ---------------------
+//
+// The reference has no counterpart (RunCascade is a single goroutine, core/pigo.go:212-258); this is north_star's batch
+// configuration: one process per GPU, contiguous shards of independent frames, no exchange during the scan, ONE collective at
+// the end.  librccl is bound at run time (dlopen) so that single-GPU users of libpigo_hip.so do not need it.
+
+#include <dlfcn.h>
+
+namespace {
+
+struct RcclUniqueId {
+    char internal[PIGO_COMM_ID_BYTES];  // == ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128)
+};
+typedef void *rccl_comm_t;
+typedef int (*fn_ncclGetUniqueId)(RcclUniqueId *);
+typedef int (*fn_ncclCommInitRank)(rccl_comm_t *, int, RcclUniqueId, int);
+typedef int (*fn_ncclCommDestroy)(rccl_comm_t);
+typedef int (*fn_ncclAllGather)(const void *, void *, size_t, int, rccl_comm_t, hipStream_t);
+typedef const char *(*fn_ncclGetErrorString)(int);
+constexpr int kNcclInt32 = 2;  // ncclDataType_t: ncclInt8 0, ncclUint8 1, ncclInt32 2 (rccl.h)
+
+struct Rccl {
+    void *h = nullptr;
+    fn_ncclGetUniqueId get_id = nullptr;
+    fn_ncclCommInitRank init_rank = nullptr;
+    fn_ncclCommDestroy destroy = nullptr;
+    fn_ncclAllGather all_gather = nullptr;
+    fn_ncclGetErrorString err = nullptr;
+};
+
+std::mutex g_rccl_mu;
+Rccl g_rccl;
+
+pigo_status rccl_load(const Rccl **out)
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (!g_rccl.h) {
+        // a process that already has RCCL (e.g. PyTorch's bundled copy, same soname) shares it; PIGO_RCCL_LIB overrides
+        const char *names[] = {getenv("PIGO_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void *h = nullptr;
+        for (const char *n : names)
+            if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) return fail(PIGO_ERR_HIP, "librccl not found (%s)", dlerror());
+        Rccl r;
+        r.h = h;
+        r.get_id = (fn_ncclGetUniqueId)dlsym(h, "ncclGetUniqueId");
+        r.init_rank = (fn_ncclCommInitRank)dlsym(h, "ncclCommInitRank");
+        r.destroy = (fn_ncclCommDestroy)dlsym(h, "ncclCommDestroy");
+        r.all_gather = (fn_ncclAllGather)dlsym(h, "ncclAllGather");
+        r.err = (fn_ncclGetErrorString)dlsym(h, "ncclGetErrorString");
+        if (!r.get_id || !r.init_rank || !r.destroy || !r.all_gather) return fail(PIGO_ERR_HIP, "librccl lacks a required symbol");
+        g_rccl = r;
+    }
+    *out = &g_rccl;
+    return PIGO_OK;
+}
+
+#define RCCL_TRY(r, expr)                                                                                   \
+    do {                                                                                                    \
+        int e_ = (expr);                                                                                    \
+        if (e_ != 0) return fail(PIGO_ERR_HIP, "%s: %s", #expr, (r)->err ? (r)->err(e_) : "rccl error");   \
+    } while (0)
+
+}  // namespace
+
+struct pigo_comm {
+    int rank = 0, world = 1, device = 0;
+    rccl_comm_t comm = nullptr;  // NULL when world == 1: nothing to exchange
+};
+
+extern "C" pigo_status pigo_comm_unique_id(uint8_t id[PIGO_COMM_ID_BYTES])
+{
+    if (!id) return fail(PIGO_ERR_PARAM, "id is NULL");
+    const Rccl *r = nullptr;
+    pigo_status st = rccl_load(&r);
+    if (st != PIGO_OK) return st;
+    RcclUniqueId u;
+    RCCL_TRY(r, r->get_id(&u));
+    memcpy(id, u.internal, PIGO_COMM_ID_BYTES);
+    return PIGO_OK;
+}
+
+extern "C" pigo_status pigo_comm_init(const uint8_t id[PIGO_COMM_ID_BYTES], int rank, int world, int device, pigo_comm **out)
+{
+    if (!out) return fail(PIGO_ERR_PARAM, "out is NULL");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(PIGO_ERR_PARAM, "rank %d outside [0, %d)", rank, world);
+    std::unique_ptr<pigo_comm> c(new (std::nothrow) pigo_comm);
+    if (!c) return fail(PIGO_ERR_NOMEM, "out of memory");
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    if (world > 1) {
+        if (!id) return fail(PIGO_ERR_PARAM, "id is NULL");
+        const Rccl *r = nullptr;
+        pigo_status st = rccl_load(&r);
+        if (st != PIGO_OK) return st;
+        HIP_TRY(hipSetDevice(device));
+        RcclUniqueId u;
+        memcpy(u.internal, id, PIGO_COMM_ID_BYTES);
+        RCCL_TRY(r, r->init_rank(&c->comm, world, u, rank));
+    }
+    *out = c.release();
+    return PIGO_OK;
+}
+
+extern "C" pigo_status pigo_comm_info(const pigo_comm *c, int *rank, int *world)
+{
+    if (!c) return fail(PIGO_ERR_PARAM, "comm is NULL");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return PIGO_OK;
+}
+
+extern "C" void pigo_comm_destroy(pigo_comm *c)
+{
+    if (!c) return;
+    if (c->comm && g_rccl.destroy) {
+        (void)hipSetDevice(c->device);
+        (void)g_rccl.destroy(c->comm);
+    }
+    delete c;
+}
+
+extern "C" void pigo_shard_bounds(int nframes, int rank, int world, int *lo, int *hi)
+{
+    if (world < 1) world = 1;
+    if (nframes < 0) nframes = 0;
+    const int base = nframes / world, rem = nframes % world;
+    const int l = rank * base + std::min(rank, rem);
+    if (lo) *lo = l;
+    if (hi) *hi = l + base + (rank < rem ? 1 : 0);
+}
+
+extern "C" size_t pigo_wire_words(int gather_cap) { return gather_cap < 0 ? 0 : 1 + 4 * (size_t)gather_cap; }
+
+extern "C" pigo_status pigo_pack_lists(const pigo_det *lists, const int32_t *counts, int nframes, int frames_out, int cap, int gather_cap,
+                                       int32_t *wire)
+{
+    if (nframes < 0 || frames_out < nframes || cap < 0 || gather_cap < 0) return fail(PIGO_ERR_PARAM, "bad list geometry");
+    if (frames_out > 0 && !wire) return fail(PIGO_ERR_PARAM, "wire is NULL");
+    if (nframes > 0 && (!counts || (!lists && cap > 0))) return fail(PIGO_ERR_PARAM, "NULL list pointer");
+    const size_t words = pigo_wire_words(gather_cap);
+    for (int f = 0; f < frames_out; ++f) {
+        int32_t *row = wire + (size_t)f * words;
+        memset(row, 0, words * 4);
+        if (f >= nframes) continue;
+        row[0] = counts[f];
+        const int n = std::max(0, std::min(std::min(counts[f], cap), gather_cap));
+        if (n) memcpy(row + 1, lists + (size_t)f * cap, (size_t)n * sizeof(pigo_det));
+    }
+    return PIGO_OK;
+}
+
+extern "C" pigo_status pigo_unpack_list(const int32_t *wire_row, int gather_cap, pigo_det *out, int cap, int *n_out, int *true_count)
+{
+    if (!wire_row || gather_cap < 0) return fail(PIGO_ERR_PARAM, "bad wire row");
+    const int cnt = wire_row[0];
+    const int n = std::max(0, std::min(cnt, gather_cap));
+    if (true_count) *true_count = cnt;
+    if (n_out) *n_out = n;
+    if (n > cap) return fail(PIGO_ERR_CAPACITY, "unpack: %d records, capacity %d", n, cap);
+    if (n && !out) return fail(PIGO_ERR_PARAM, "out is NULL");
+    if (n) memcpy(out, wire_row + 1, (size_t)n * sizeof(pigo_det));
+    return PIGO_OK;
+}
+
+extern "C" pigo_status pigo_run_batch_sharded(pigo_plan *p, pigo_comm *comm, const uint8_t *d_frames, size_t frame_stride, int nframes_local,
+                                              int frames_per_rank, double iou_threshold, int gather_cap, int32_t *d_gathered, void *stream)
+{
+    if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
+    if (nframes_local < 0 || nframes_local > p->max_frames || frames_per_rank < nframes_local || frames_per_rank < 1)
+        return fail(PIGO_ERR_PARAM, "need 0 <= nframes_local <= min(max_frames, frames_per_rank)");
+    if (gather_cap < 1 || gather_cap > p->det_cap) return fail(PIGO_ERR_PARAM, "gather_cap outside [1, det_cap]");
+    if (!d_gathered) return fail(PIGO_ERR_PARAM, "d_gathered is NULL");
+    const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
+    if (comm && comm->device != p->c->device) return fail(PIGO_ERR_PARAM, "communicator and plan live on different devices");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(p->c->device));
+    const size_t words = pigo_wire_words(gather_cap);
+    {
+        std::lock_guard<std::mutex> lock(p->mu);
+        const size_t need = (size_t)p->max_frames * p->det_cap;
+        if (p->sh_dets.n < need) HIP_TRY(p->sh_dets.alloc(need));
+        if (p->sh_counts.n < (size_t)p->max_frames * 2) HIP_TRY(p->sh_counts.alloc((size_t)p->max_frames * 2));
+        if (p->sh_wire.n < (size_t)frames_per_rank * words) HIP_TRY(p->sh_wire.alloc((size_t)frames_per_rank * words));
+    }
+    const bool clustered = iou_threshold == iou_threshold && iou_threshold >= 0.0;  // NaN / negative: gather the raw RunCascade lists
+    if (clustered) {
+        std::lock_guard<std::mutex> lock(p->mu);
+        const size_t need = (size_t)p->max_frames * p->det_cap;
+        if (p->sh_sorted.n < need) HIP_TRY(p->sh_sorted.alloc(need));
+        if (p->sh_clusters.n < need) HIP_TRY(p->sh_clusters.alloc(need));
+    }
+    int32_t *d_counts = p->sh_counts.p, *d_ccounts = p->sh_counts.p + p->max_frames;
+    const pigo_det *lists = p->sh_dets.p;
+    const int32_t *lcounts = d_counts;
+    if (nframes_local > 0) {
+        pigo_status st = pigo_plan_run(p, d_frames, frame_stride, nframes_local, p->sh_dets.p, d_counts, stream);
+        if (st != PIGO_OK) return st;
+        if (clustered) {
+            st = pigo_plan_cluster(p, p->sh_dets.p, d_counts, nframes_local, iou_threshold, p->sh_sorted.p, p->sh_clusters.p, d_ccounts, nullptr,
+                                   stream);
+            if (st != PIGO_OK) return st;
+            lists = p->sh_clusters.p;
+            lcounts = d_ccounts;
+        }
+    }
+    k_pack_lists<<<frames_per_rank, 256, 0, s>>>(lists, lcounts, nframes_local, p->det_cap, gather_cap, p->sh_wire.p);
+    HIP_TRY(hipGetLastError());
+    const size_t row_words = (size_t)frames_per_rank * words;
+    if (world > 1) {
+        const Rccl *r = nullptr;
+        pigo_status st = rccl_load(&r);
+        if (st != PIGO_OK) return st;
+        RCCL_TRY(r, r->all_gather(p->sh_wire.p, d_gathered, row_words, kNcclInt32, comm->comm, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_gathered + (size_t)rank * row_words, p->sh_wire.p, row_words * 4, hipMemcpyDeviceToDevice, s));
+    }
+    return PIGO_OK;
 }

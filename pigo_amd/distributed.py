@@ -7,23 +7,31 @@ RCCL has no all-gather-v, so each frame contributes ``1 + 4*gather_cap`` int32 w
 followed by ``gather_cap`` 16-byte records (row, col, scale, q-bits); frames with more detections than
 ``gather_cap`` are visible as ``count > gather_cap``.
 
-The packing / gathering code is backend-agnostic (works on CPU tensors with gloo), which is how the
-tests exercise the N > 1 path without GPUs.
+Two ways to run it, same wire format:
+  * ``Comm`` + ``run_batch_sharded`` -- the C ABI (include/pigo_hip.h: pigo_comm_init / pigo_run_batch_sharded): scan,
+    cluster, pack and ONE ``ncclAllGather`` issued by libpigo_hip.so itself on the caller's stream.  This is what a Go or
+    C++ host uses and what bench.py times; only the 128-byte RCCL id travels through the host program's own channel
+    (here: ``torch.distributed``'s store).
+  * ``allgather_lists`` -- the same rows through ``torch.distributed.all_gather_into_tensor`` (RCCL when the backend is
+    "nccl"); backend-agnostic, it also runs on CPU tensors with gloo, which is how the tests cover N > 1 without GPUs.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import core
 
 
 def shard_bounds(nframes: int, rank: int, world: int):
-    """Contiguous shard [lo, hi) of `nframes` frames for `rank`; earlier ranks take the remainder."""
+    """Contiguous shard [lo, hi) of `nframes` frames for `rank`; earlier ranks take the remainder (== pigo_shard_bounds)."""
     base, rem = divmod(nframes, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
 
 
 def pack_lists(dets, counts, gather_cap: int):
-    """dets int32 [n, cap, 4], counts int32 [n] -> int32 [n, 1 + 4*gather_cap] wire records."""
+    """dets int32 [n, cap, 4], counts int32 [n] -> int32 [n, 1 + 4*gather_cap] wire rows: the true count, then the first
+    min(count, gather_cap) records, zero-padded (the layout k_pack_lists / pigo_pack_lists produce)."""
     import torch
     n, cap = dets.shape[0], dets.shape[1]
     if gather_cap > cap:
@@ -31,8 +39,84 @@ def pack_lists(dets, counts, gather_cap: int):
     g = gather_cap
     wire = torch.zeros((n, 1 + 4 * gather_cap), dtype=torch.int32, device=dets.device)
     wire[:, 0] = counts
-    wire[:, 1:1 + 4 * g] = dets[:, :g, :].reshape(n, 4 * g)
+    keep = torch.arange(g, device=dets.device).unsqueeze(0) < counts.clamp(max=g).unsqueeze(1)  # [n, g]
+    wire[:, 1:1 + 4 * g] = (dets[:, :g, :] * keep.unsqueeze(-1).to(dets.dtype)).reshape(n, 4 * g)
     return wire
+
+
+class Comm:
+    """pigo_comm (include/pigo_hip.h): this rank's handle on the RCCL communicator libpigo_hip.so uses for the all-gather.
+
+    ``Comm.from_torch(device)`` builds it inside an initialised ``torch.distributed`` job: rank 0 asks the library for the
+    RCCL id and the process group only carries those 128 bytes to the other ranks."""
+
+    def __init__(self, rank: int, world: int, device: int, unique_id: bytes = None):
+        self.L = core.load_library()
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        h = C.c_void_p()
+        idbuf = (C.c_uint8 * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        core.check(self.L.pigo_comm_init(idbuf, self.rank, self.world, self.device, C.byref(h)), "comm_init")
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and core._lib is not None:
+            core._lib.pigo_comm_destroy(h)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        core.check(core.load_library().pigo_comm_unique_id(buf), "comm_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def from_torch(cls, device: int, group=None):
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 and world > 1 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        return cls(rank, world, device, box[0])
+
+
+def run_batch_sharded(plan, comm, frames, frames_per_rank: int, iou: float, gather_cap: int, out=None, stream=None):
+    """pigo_run_batch_sharded: scan this rank's ``frames`` (uint8 [n, rows, dim] on the GPU, n <= frames_per_rank),
+    cluster per frame (iou >= 0; a negative iou gathers the raw lists) and all-gather the wire rows of all ranks.
+    Returns the int32 [world*frames_per_rank, 1 + 4*gather_cap] tensor (``out`` to reuse it).  Asynchronous on the current
+    stream; ``plan.status()`` applies after synchronising."""
+    import torch
+    from .batch import ScanPlan
+    n, stride = plan._check_frames(frames) if frames is not None and frames.shape[0] else (0, plan.rows * plan.dim)
+    world = comm.world if comm is not None else 1
+    words = 1 + 4 * int(gather_cap)
+    if out is None:
+        out = torch.zeros((world * frames_per_rank, words), dtype=torch.int32, device=torch.device("cuda", plan.device))
+    assert out.dtype == torch.int32 and out.is_cuda and out.is_contiguous() and tuple(out.shape) == (world * frames_per_rank, words)
+    core.check(plan.L.pigo_run_batch_sharded(plan._h, comm._h if comm is not None else None,
+                                             C.c_void_p(frames.data_ptr()) if n else None, stride, n, int(frames_per_rank), float(iou),
+                                             int(gather_cap), C.c_void_p(out.data_ptr()), ScanPlan._stream_ptr(stream)), "run_batch_sharded")
+    return out
+
+
+def pack_lists_host(dets: np.ndarray, counts: np.ndarray, frames_out: int, gather_cap: int) -> np.ndarray:
+    """pigo_pack_lists on host arrays: dets DET_DTYPE [n, cap], counts int32 [n] -> int32 [frames_out, 1 + 4*gather_cap]."""
+    dets = np.ascontiguousarray(dets)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    n, cap = dets.shape
+    wire = np.zeros((frames_out, 1 + 4 * gather_cap), dtype=np.int32)
+    core.check(core.load_library().pigo_pack_lists(dets.ctypes.data, counts.ctypes.data, n, frames_out, cap, gather_cap, wire.ctypes.data),
+               "pack_lists")
+    return wire
+
+
+def unpack_list_host(row: np.ndarray, gather_cap: int):
+    """pigo_unpack_list: one wire row -> (Detection array, true count)."""
+    row = np.ascontiguousarray(row, dtype=np.int32)
+    out = np.zeros(max(gather_cap, 1), dtype=core.DET_DTYPE)
+    n, cnt = C.c_int(0), C.c_int(0)
+    core.check(core.load_library().pigo_unpack_list(row.ctypes.data, gather_cap, out.ctypes.data, len(out), C.byref(n), C.byref(cnt)),
+               "unpack_list")
+    return out[: n.value].copy(), cnt.value
 
 
 def unpack_lists(wire, gather_cap: int):

@@ -48,6 +48,39 @@ def _worker(rank, world, port, nframes, cap, gcap, ret):
         dist.destroy_process_group()
 
 
+def _worker_cabi(rank, world, port, nframes, cap, gcap, ret):
+    """The same exchange with the C ABI's host-side wire functions (pigo_shard_bounds / pigo_pack_lists /
+    pigo_unpack_list, include/pigo_hip.h) doing what k_pack_lists does on the device; gloo stands in for ncclAllGather."""
+    import ctypes as C
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L = core.load_library()
+        lo, hi = C.c_int(0), C.c_int(0)
+        L.pigo_shard_bounds(nframes, rank, world, C.byref(lo), C.byref(hi))
+        ok = (lo.value, hi.value) == distributed.shard_bounds(nframes, rank, world)
+        dets, counts = _fake_lists(lo.value, hi.value, cap)
+        idx, per = distributed.gathered_frame_index(nframes, world)
+        wire = distributed.pack_lists_host(dets.numpy().view(core.DET_DTYPE).reshape(hi.value - lo.value, cap), counts.numpy(), per, gcap)
+        ok &= wire.shape == (per, int(L.pigo_wire_words(gcap)))
+        ref = distributed.pack_lists(dets, counts, gcap).numpy()  # the torch path writes the same rows
+        ok &= bool((wire[: hi.value - lo.value] == ref).all()) and bool((wire[hi.value - lo.value:] == 0).all())
+        out = torch.empty((world * per, wire.shape[1]), dtype=torch.int32)
+        dist.all_gather_into_tensor(out, torch.from_numpy(wire))
+        for row, f in enumerate(idx.tolist()):
+            lst, cnt = distributed.unpack_list_host(out[row].numpy(), gcap)
+            if f < 0:
+                ok &= cnt == 0 and len(lst) == 0
+                continue
+            k = (f * 7) % (cap + 3)
+            ok &= cnt == k and len(lst) == min(k, gcap, cap)
+            for j, d in enumerate(lst):
+                ok &= (int(d["row"]), int(d["col"]), int(d["scale"])) == (f, j, 20 + j) and d["q"] == np.float32(f + j / 10.0)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -60,6 +93,43 @@ def test_allgather_lists_gloo_world2():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), nframes, cap, gcap, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_c_abi_wire_format_gloo_world2():
+    world, nframes, cap, gcap = 2, 7, 12, 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_cabi, args=(world, _free_port(), nframes, cap, gcap, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_comm_world1_needs_no_rccl_and_no_gpu():
+    """pigo_comm_init(world = 1) is a plain handle: nothing to exchange, RCCL is not even loaded."""
+    import pytest
+    c = distributed.Comm(0, 1, 0)
+    import ctypes as C
+    r, w = C.c_int(-1), C.c_int(-1)
+    core.check(core.load_library().pigo_comm_info(c._h, C.byref(r), C.byref(w)))
+    assert (r.value, w.value) == (0, 1)
+    with pytest.raises(ValueError):
+        distributed.Comm(2, 2, 0, bytes(128))  # rank outside [0, world)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 ranks itself (torch.distributed.run) and report
+    n_gpus 2 with the all-gather inside the step; --cpu-dry-run swaps the GPU scan for fabricated lists and RCCL for gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-dry-run", "--steps", "2", "--warmup", "1",
+                        "--frames", "5"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["ranks_seen"] == [0, 1] and d["gathered_rows"] == 10
 
 
 def test_pack_unpack_roundtrip():

@@ -18,6 +18,10 @@ pytestmark = pytest.mark.gpu
 Q_TOL_CONTRACT = 1e-5  # north_star: "within 1e-5 on the float q score"
 Q_TOL_RAW = 0.0        # design target: bit-exact
 
+# scan implementations of the release library: 2 = LDS tiles (default), 0 = monolithic fallback.  Variant 1 (the first
+# head + tail design) is compiled into the debug build only (python -m pigo_amd.build --debug; PIGO_HIP_LIB selects it).
+VARIANTS = [2, 0] + ([1] if "debug" in core.library_path() else [])
+
 
 def _cp(img, rows, cols, dim, mn, mx, shift, scale):
     return core.CascadeParams(MinSize=mn, MaxSize=mx, ShiftFactor=shift, ScaleFactor=scale,
@@ -48,7 +52,7 @@ def test_unpack_tables_match_oracle(pg, orc):
 # ---- RunCascade + ClusterDetections against the goldens (both scan variants) -----------------------------------
 
 
-@pytest.mark.parametrize("variant", [2, 1, 0])
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_golden_cases(pg, golden, variant, monkeypatch):
     monkeypatch.setenv("PIGO_SCAN_VARIANT", str(variant))
     fresh = core.NewPigo(0).Unpack(synth.facefinder_bytes())  # new handle: plans are cached per handle
@@ -72,7 +76,7 @@ def test_reference_test_invariants(pg, gray):
 # ---- seeded sweeps against the oracle -------------------------------------------------------------------------
 
 
-@pytest.mark.parametrize("variant", [2, 1, 0])
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_random_parameter_sweep(orc, variant, monkeypatch):
     monkeypatch.setenv("PIGO_SCAN_VARIANT", str(variant))
     fresh = core.NewPigo(0).Unpack(synth.facefinder_bytes())
@@ -184,7 +188,7 @@ def test_batch_api_matches_single_frame_and_is_order_stable(pg, orc):
     dev = torch.device("cuda", 0)
     d_frames = torch.from_numpy(frames).to(dev)
     want = [orc.run_cascade(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1, 0.0) for f in range(n)]
-    for variant in (2, 1, 0):
+    for variant in VARIANTS:
         plan = batch.ScanPlan(pg, rows, cols, MinSize=20, MaxSize=1000, ShiftFactor=0.1, ScaleFactor=1.1, max_frames=n, det_cap=512)
         plan.set_variant(variant)
         dets, counts = plan.alloc_outputs(n)
@@ -291,14 +295,14 @@ def test_queue_overflow_falls_back_to_monolithic(orc, monkeypatch):
     kernel -- same result, no silent truncation."""
     import torch
     from pigo_amd import batch
-    monkeypatch.setenv("PIGO_QUEUE_DIV", "100000")  # queue capacity = the 4096-entry floor
-    monkeypatch.setenv("PIGO_SCAN_VARIANT", "1")     # the survivor queue belongs to variant 1
+    monkeypatch.setenv("PIGO_QUEUE_DIV", "100000000")  # queue capacity = the floor ...
+    monkeypatch.setenv("PIGO_QUEUE_MIN", "8")           # ... of 8 entries per frame: the per-XCD survivor queues hold 2 entries each
     fresh = core.NewPigo(0).Unpack(synth.facefinder_bytes())
     rows, cols = 540, 960
-    f = synth.make_frames("noise", 2, rows, cols, seed=5)
+    f = synth.make_frames("faces", 2, rows, cols, seed=5)
     d_frames = torch.from_numpy(f).to("cuda:0")
     plan = batch.ScanPlan(fresh, rows, cols, max_frames=2, det_cap=256)
-    assert plan.info().queue_capacity <= 8192
+    assert plan.info().queue_capacity <= 1024 and plan.info().variant == 2
     dets, counts = plan.alloc_outputs(2)
     plan.run(d_frames, dets, counts)
     torch.cuda.synchronize()
@@ -308,6 +312,30 @@ def test_queue_overflow_falls_back_to_monolithic(orc, monkeypatch):
     got = batch.dets_to_numpy(dets, counts)
     for k in range(2):
         assert_same_dets(got[k], orc.run_cascade(f[k], rows, cols, cols, 20, 1000, 0.1, 1.1, 0.0), f"fallback frame {k}", Q_TOL_RAW)
+
+
+def test_batch_detection_overflow_is_reported_not_silent(pg):
+    """A frame with more than det_cap detections on the asynchronous batch path: the list is truncated (which records
+    survive depends on atomic order), so pigo_plan_status must say so -- PIGO_ERR_CAPACITY -- and d_counts must hold the
+    true count."""
+    import torch
+    from pigo_amd import batch
+    f = synth.make_frames("faces", 3, 1080, 1920, seed=1234)
+    d_frames = torch.from_numpy(f).cuda()
+    plan = batch.ScanPlan(pg, 1080, 1920, max_frames=3, det_cap=16)
+    dets, counts = plan.alloc_outputs(3)
+    plan.run(d_frames, dets, counts)
+    torch.cuda.synchronize()
+    with pytest.raises(core.PigoError, match="det_cap"):
+        plan.status()
+    assert int(counts.max()) > 16
+    plan.status()  # the flag is cleared by the report
+    big = batch.ScanPlan(pg, 1080, 1920, max_frames=3, det_cap=int(counts.max()))
+    d2, c2 = big.alloc_outputs(3)
+    big.run(d_frames, d2, c2)
+    torch.cuda.synchronize()
+    big.status()
+    assert torch.equal(c2, counts)
 
 
 def test_detection_capacity_is_reported(pg):
@@ -328,7 +356,7 @@ def test_4k_config5_variants_agree_and_match_oracle(pg, orc):
     f = synth.make_frames("faces", 1, 2160, 3840, seed=1234)
     d_frames = torch.from_numpy(f).to("cuda:0")
     res = {}
-    for variant in (2, 1, 0):
+    for variant in VARIANTS:
         plan = batch.ScanPlan(pg, 2160, 3840, MinSize=20, MaxSize=2000, ShiftFactor=0.05, ScaleFactor=1.05, max_frames=1, det_cap=32768)
         plan.set_variant(variant)
         assert plan.info().windows_per_frame == 113382193 and plan.info().n_scales == 96
@@ -337,12 +365,12 @@ def test_4k_config5_variants_agree_and_match_oracle(pg, orc):
         torch.cuda.synchronize()
         plan.status()  # no queue overflow, i.e. no silent trip through the monolithic fallback, on the step-1 scales
         res[variant] = batch.dets_to_numpy(dets, counts, 0)
-    assert_same_dets(res[1], res[0], "4K v1 vs v0", Q_TOL_RAW)
-    assert_same_dets(res[2], res[0], "4K v2 vs v0", Q_TOL_RAW)
+    for v in VARIANTS[1:]:
+        assert_same_dets(res[v], res[2], f"4K v{v} vs v2", Q_TOL_RAW)
     want = orc.run_cascade(f[0], 2160, 3840, 3840, 20, 2000, 0.05, 1.05, 0.0)  # ~15 s of CPU
-    assert_same_dets(res[1], want, "4K vs oracle", Q_TOL_RAW)
+    assert_same_dets(res[2], want, "4K vs oracle", Q_TOL_RAW)
     wc, ties = orc.cluster_detections(want.copy(), 0.2, want_ties=True)
-    got = pg.ClusterDetections(res[1].copy(), 0.2)
+    got = pg.ClusterDetections(res[2].copy(), 0.2)
     assert_same_dets(got, wc, f"4K clusters (ties={ties})", Q_TOL_RAW)
 
 
@@ -362,3 +390,81 @@ def test_cpp_mirror_runs_on_gpu(tmp_path):
     r = subprocess.run([exe, os.path.join(root, "pigo_amd", "data", "facefinder"), os.path.join(root, "pigo_amd", "data", "sample_gray_320x400.bin"),
                         os.path.join(root, "pigo_amd", "data", "puploc")], capture_output=True, text=True)
     assert r.returncode == 0 and "dets=4 clusters=1 (206,154,261," in r.stdout and "gray177=1" in r.stdout and "eye_ok=1" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+# ---- the path bench.py times: many 1080p frames, chunked pipeline, side stream, per-XCD queues -----------------------------
+
+
+@pytest.mark.parametrize("chunks,angle", [(0, 0.0), (4, 0.0), (0, 0.8)])
+def test_benchmarked_path_1080p_batch_against_oracle(pg, orc, chunks, angle, monkeypatch):
+    """ScanPlan.run + plan.cluster on 40 x 1080p frames (faces + noise mix) exactly as bench.py drives them -- default
+    chunking (and 4 chunks), global-gather classes on the side stream, frames dealt to the eight per-XCD survivor queues --
+    every frame compared with the oracle (run on host threads), raw lists and clusters, bit-exact.  core/pigo.go:212-308."""
+    import threading
+    import torch
+    from pigo_amd import batch
+    monkeypatch.setenv("PIGO_PIPE_CHUNKS", str(chunks))
+    n, rows, cols = 40, 1080, 1920
+    frames = np.concatenate([synth.make_frames("faces", 34, rows, cols, seed=1234), synth.make_frames("noise", 6, rows, cols, seed=99)])
+    d_frames = torch.from_numpy(frames).cuda()
+    want, wantc = [None] * n, [None] * n
+
+    def work(lo, hi):
+        for f in range(lo, hi):
+            want[f] = orc.run_cascade(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1, angle)
+            wantc[f] = orc.cluster_detections(want[f].copy(), 0.2, want_ties=True)
+
+    th = [threading.Thread(target=work, args=(k, k + 1)) for k in range(n)]  # ctypes releases the GIL: one core per frame
+    for t in th:
+        t.start()
+    plan = batch.ScanPlan(pg, rows, cols, MinSize=20, MaxSize=1000, ShiftFactor=0.1, ScaleFactor=1.1, angle=angle, max_frames=n, det_cap=1024)
+    dets, counts = plan.alloc_outputs(n)
+    cl_out = plan.alloc_cluster_outputs(dets, counts)
+    for rep in range(2):  # the second run reuses every queue, counter and event of the first
+        plan.run(d_frames, dets, counts)
+        sorted_, clusters, ccounts, ties = plan.cluster(dets, counts, 0.2, out=cl_out)
+    torch.cuda.synchronize()
+    plan.status()
+    assert int(counts.max()) <= 1024
+    for t in th:
+        t.join()
+    got = batch.dets_to_numpy(dets, counts)
+    cl = batch.dets_to_numpy(clusters, ccounts)
+    for f in range(n):
+        assert_same_dets(got[f], want[f], f"1080p batch chunks={chunks} angle={angle} frame {f}", Q_TOL_RAW)
+        assert int(ties[f]) == wantc[f][1]
+        assert_same_dets(cl[f], wantc[f][0], f"1080p batch clusters frame {f} (ties={wantc[f][1]})", Q_TOL_RAW)
+    assert sum(len(w) for w in want) > (1000 if angle == 0.0 else 20)
+
+
+def test_sharded_entry_point_world1_matches_plain_path(pg, orc):
+    """pigo_run_batch_sharded (the C ABI a Go / C++ host shards with) at world size 1: scan + cluster + device-side
+    packing must give exactly the wire rows of the plain path's lists, padding rows included; raw-list mode as well."""
+    import torch
+    from pigo_amd import batch, distributed
+    n, per, rows, cols, gcap = 11, 16, 270, 480, 8
+    frames = synth.make_frames("faces", n, rows, cols, seed=21)
+    d_frames = torch.from_numpy(frames).cuda()
+    plan = batch.ScanPlan(pg, rows, cols, max_frames=16, det_cap=256)
+    dets, counts = plan.alloc_outputs(n)
+    plan.run(d_frames, dets, counts)
+    _, clusters, ccounts, _ = plan.cluster(dets, counts, 0.2)
+    torch.cuda.synchronize()
+    comm = distributed.Comm(0, 1, 0)
+    for iou, lists, lcounts in ((0.2, clusters, ccounts), (-1.0, dets, counts)):
+        wire = distributed.run_batch_sharded(plan, comm, d_frames, per, iou, gcap)
+        torch.cuda.synchronize()
+        plan.status()
+        ref = distributed.pack_lists(lists, lcounts, gcap)
+        assert tuple(wire.shape) == (per, 1 + 4 * gcap)
+        assert torch.equal(wire[:n], ref) and int(wire[n:].abs().sum()) == 0
+        host = distributed.pack_lists_host(batch_lists_to_host(lists, n), lcounts.cpu().numpy(), per, gcap)
+        assert (host == wire.cpu().numpy()).all()
+    want0 = orc.cluster_detections(orc.run_cascade(frames[0], rows, cols, cols, 20, 1000, 0.1, 1.1, 0.0), 0.2)
+    got0, cnt0 = distributed.unpack_list_host(distributed.run_batch_sharded(plan, comm, d_frames, per, 0.2, gcap)[0].cpu().numpy(), gcap)
+    assert cnt0 == len(want0)
+    assert_same_dets(got0, want0[:gcap], "sharded frame 0", Q_TOL_RAW)
+
+
+def batch_lists_to_host(lists, n):
+    return lists[:n].cpu().numpy().view(core.DET_DTYPE).reshape(n, lists.shape[1])

@@ -148,3 +148,42 @@ def test_batch_requests_over_device_frames():
     with pytest.raises(core.PigoPanic):
         batch.puploc_status(h)
     batch.puploc_status(h)  # the flag is cleared by reading it
+
+
+def test_batch_requests_on_padded_frames_clamp_with_cols_not_dim():
+    """Frames with Dim > Cols (the output of rgb_to_grayscale(dim=...)): the column clamp min(ncols-1, ...) of
+    puploc.go:118-128 must use ImageParams.Cols, not the stride -- requests near the right border would otherwise read
+    the padding bytes.  ADVICE r1: puploc_run_batch(cols=...)."""
+    import torch
+    from pigo_amd import batch
+    rows, cols, dim, nf = 200, 300, 352, 3
+    frames = np.full((nf, rows, dim), 255, dtype=np.uint8)  # bright padding: a clamp that lands in it changes the comparisons
+    frames[:, :, :cols] = synth.make_frames("faces", nf, rows, cols, seed=5)
+    d_frames = torch.from_numpy(frames).cuda()
+    pk = synth.cascade_bytes("puploc")
+    h, o = core.NewPuplocCascade(0).UnpackCascade(pk), oracle.OraclePuploc.unpack(pk)
+    rng = np.random.default_rng(3)
+    n = 120
+    reqs = np.zeros(n, dtype=core.PUPLOC_REQ_DTYPE)
+    reqs["row"], reqs["col"] = rng.integers(0, rows, n), rng.integers(cols - 40, cols + 10, n)  # hugging the right border
+    reqs["scale"] = rng.uniform(20, 90, n).astype(np.float32)
+    reqs["perturbs"] = 63
+    reqs["frame"], reqs["flip_v"] = rng.integers(0, nf, n), rng.integers(0, 2, n)
+    rnd = np.stack([synth.syn_uniform32(189, seed=9, index=i) for i in range(n)])
+    d_reqs = torch.from_numpy(reqs.view(np.uint8).reshape(n, 24)).cuda()
+    d_rnd = torch.from_numpy(rnd).cuda()
+    differs = 0
+    for angle in (0.0, 0.3):
+        out = batch.puploc_run_batch(h, d_frames, d_reqs, d_rnd, angle=angle, cols=cols)
+        torch.cuda.synchronize()
+        batch.puploc_status(h)
+        got = out.cpu().numpy().view(core.PUPLOC_DTYPE).reshape(n)
+        for i in range(n):
+            r = reqs[i]
+            want = o.run_detector(int(r["row"]), int(r["col"]), float(r["scale"]), 63, frames[r["frame"]], rows, cols, dim, angle,
+                                  bool(r["flip_v"]), rnd[i], None)
+            assert (int(got[i]["row"]), int(got[i]["col"])) == want[:2] and got[i]["scale"] == want[2], (angle, i, got[i], want)
+            wrong = o.run_detector(int(r["row"]), int(r["col"]), float(r["scale"]), 63, frames[r["frame"]], rows, dim, dim, angle,
+                                   bool(r["flip_v"]), rnd[i], None)
+            differs += wrong != want
+    assert differs > 0  # the test would not notice the bug otherwise
