@@ -533,7 +533,7 @@ void build_tile_classes(pigo_plan &p)
         sd.pitch = 0;
         // LDS queues: 1.5 tiles' worth of entries shared by the two ping-pong regions; an overflow (stage 0 and stage 1
         // survivors together exceeding that) is caught on the device
-        const int qb_div = p.rot ? (env_int("PIGO_ROT_QB_DIV", 2) == 1 ? 1 : 2) : (env_int("PIGO_QB_DIV", 2) == 1 ? 1 : 2);
+        const int qb_div = p.rot ? (env_int("PIGO_ROT_QB_DIV", 1) == 1 ? 1 : 2) : (env_int("PIGO_QB_DIV", 2) == 1 ? 1 : 2);
         Pick pk{g_tw_log2, g_th, false, 0, 0, qb_div};
         if (lds_allowed) {
             for (const TileRule &r : rules) {
@@ -937,7 +937,12 @@ pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame
     if (variant >= 1) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)std::max(nframes, 16) * 4, s));
 
     size_t ev = 0;
+    static const bool sync_debug = env_int("PIGO_SYNC_DEBUG", 0) != 0;  // debugging aid: synchronise and report before every kernel
     auto mark = [&](const char *name) {
+        if (sync_debug) {
+            const hipError_t e = hipDeviceSynchronize();
+            fprintf(stderr, "[pigo] before %s: %s\n", name, hipGetErrorString(e));
+        }
         if (!p->profiling) return;
         if (ev >= p->events.size()) {
             hipEvent_t e;
@@ -1038,7 +1043,9 @@ extern "C" pigo_status pigo_plan_status(pigo_plan *p)
     p->last_flags[1] = flags[1];
     p->last_flags[2] = flags[2];
     if (flags[1]) return fail(PIGO_ERR_PANIC, "the reference would panic: pixel index out of range in classifyRotatedRegion (pigo.go:167-179)");
-    if (flags[0]) return fail(PIGO_ERR_CAPACITY, "survivor queue overflow");
+    if (flags[0])
+        return fail(PIGO_ERR_CAPACITY, "survivor queue overflow (%s%s%s)", (flags[0] & 1) ? "tile LDS queue " : "", (flags[0] & 2) ? "survivor queue " : "",
+                    (flags[0] & 4) ? "second-level tail queue" : "");
     if (flags[2]) return fail(PIGO_ERR_CAPACITY, "a frame has more than det_cap (%d) detections: its list is truncated (d_counts holds the true count)", p->det_cap);
     return PIGO_OK;
 }
