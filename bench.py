@@ -354,6 +354,7 @@ def main():
         tiles = max(st[4], 1)
         print("debug_stats (cycles per tile): copy %.0f stage0 %.0f dense %.0f late %.0f | late windows/tile %.1f late trees/tile %.1f tiles %d" %
               (st[0] / tiles, st[1] / tiles, st[2] / tiles, st[3] / tiles, st[5] / tiles, st[6] / tiles, st[4]), file=sys.stderr)
+        print("debug_stats raw:", st, file=sys.stderr)
         ne = max(st[8], 1)
         print("debug_stats tail_deep (wave 0): %.0f cycles per entry | passes/entry %.2f entries %d" % (st[9] / ne, st[14] / ne, st[8]), file=sys.stderr)
     ndet = int(counts.sum().item())

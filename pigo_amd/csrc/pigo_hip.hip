@@ -137,10 +137,20 @@ struct pigo_plan {
         bool lds;
         uint32_t tile0, ntiles;
         size_t dyn_lds;
+        uint32_t v3_skip;                // variant 3: leading tiles of this class that belong to rungs the region kernel scans
     };
     std::vector<TileClass> classes;
     std::vector<uint2> tiles2;
     DevBuf<uint2> d_tiles2;
+    // variant 3 (k_scan_region): scale groups, each scanned by one launch of 1024-thread workgroups that own an LDS-resident
+    // region of a frame; rungs beyond the last group keep k_scan_tile's global-gather class
+    struct RegionGroup {
+        RegionArgs args;
+        size_t dyn_lds;
+    };
+    std::vector<RegionGroup> regions;
+    bool region_ok = false;
+    DevBuf<uint32_t> d_tabr;
     DevBuf<uint32_t> d_tabp;
     bool tile_ok = false;
     int tab_lds = 0, tab_glb = 0;        // LDS table capacity (trees) of the LDS-pixel / global-pixel classes
@@ -566,7 +576,7 @@ void build_tile_classes(pigo_plan &p)
     std::vector<char> done(p.scales.size(), 0);
     for (size_t k = 0; k < p.scales.size(); ++k) {
         if (done[k]) continue;
-        pigo_plan::TileClass cls{picks[k].tw_log2, picks[k].th, (1 << picks[k].tw_log2) * picks[k].th, picks[k].qb_div, picks[k].lds, (uint32_t)p.tiles2.size(), 0, 0};
+        pigo_plan::TileClass cls{picks[k].tw_log2, picks[k].th, (1 << picks[k].tw_log2) * picks[k].th, picks[k].qb_div, picks[k].lds, (uint32_t)p.tiles2.size(), 0, 0, 0};
         for (size_t j = k; j < p.scales.size(); ++j) {
             const Pick &q = picks[j];
             if (done[j] || q.tw_log2 != cls.tw_log2 || q.th != cls.th || q.lds != cls.lds || q.bucket != picks[k].bucket || q.qb_div != cls.qb_div) continue;
@@ -581,6 +591,98 @@ void build_tile_classes(pigo_plan &p)
         cls.ntiles = (uint32_t)p.tiles2.size() - cls.tile0;
         p.classes.push_back(cls);
     }
+}
+
+// Variant 3: cut the scale ladder into groups by footprint and the image into cells whose region (cell + halo) fits the LDS
+// next to the tables and queues of k_scan_region.  Returns false when the plan is not eligible (rotated scan, stride not a
+// multiple of 4, cascade without a usable stage list).
+bool build_region_groups(pigo_plan &p)
+{
+    p.regions.clear();
+    const ScanArgs &a = p.args;
+    if (!p.tile_ok || p.rot || p.key.dim % 4 != 0 || p.scales.empty()) return false;
+    const int nh = std::min(a.nh_lds, a.nh_glb);
+    if (nh < 1 || nh > kTabTrees || a.deep_lo != nh) return false;
+    // chunk stages: the leading stages that end below the pooling tree
+    const int t_pool_wanted = std::max(1, env_int("PIGO_REG_POOL_TREE", 4));
+    int n_cs = 0;
+    while (n_cs < a.n_stages && a.st_end[n_cs] < t_pool_wanted && a.st_end[n_cs] < nh) ++n_cs;
+    if (n_cs < 1) return false;
+    const int t_pool = a.st_end[n_cs - 1] + 1;
+    const int pool_cap = kRegWavePool;
+    // leaves + raw codes of the nh trees, per wave a queue of kRegWaveChunk 6-byte and a pool of kRegWavePool 8-byte entries;
+    // plus, per group, the offset tables of the chunk-stage trees of every scale of the group
+    const int chunkg[2] = {std::min(kRegWaveChunk, std::max(64, env_int("PIGO_REG_CHUNK0", 512) & ~63)),
+                           std::min(kRegWaveChunk, std::max(64, env_int("PIGO_REG_CHUNK1", 128) & ~63))};
+    const int deepg[2] = {std::max(64, env_int("PIGO_REG_DEEP0", 1536)), std::max(64, env_int("PIGO_REG_DEEP1", 512))};
+    const size_t max_dyn = (size_t)(160 << 10) - 3072;  // static LDS of k_scan_region: per-scale geometry, counters, thresholds
+    const int smax[2] = {env_int("PIGO_REG_S0", 62), env_int("PIGO_REG_S1", 135)};
+    const int cwmax[2] = {env_int("PIGO_REG_CW0", 320), env_int("PIGO_REG_CW1", 256)};
+    int k = 0;
+    const int nscales = (int)p.scales.size();
+    for (int g = 0; g < 2 && k < nscales; ++g) {
+        const int k_lo = k;
+        int up = 0, dn = 0;
+        while (k < nscales && p.scales[k].s <= smax[g]) {
+            up = std::max(up, (p.scales[k].s + 1) / 2);
+            dn = std::max(dn, (127 * p.scales[k].s) >> 8);
+            ++k;
+        }
+        if (k == k_lo) continue;
+        if (k - k_lo > kRegMaxScales) return false;
+        const size_t fixed = (size_t)nh * 64 * 8 + (size_t)(kRegThreads / 64) * ((size_t)chunkg[g] * 6 + kRegWavePool * 8) + (size_t)deepg[g] * 8 +
+                             (size_t)(k - k_lo) * t_pool * 256;
+        if (fixed + 16384 > max_dyn) return false;
+        const size_t budget = max_dyn - fixed;
+        const int halo = up + dn;
+        // the largest cell whose region fits; then as many equal cells as the image needs; more, smaller cells when the
+        // plan's batch is too small to give every CU a workgroup
+        double shrink = 1.0;
+        RegionArgs r{};
+        for (;;) {
+            int cw_max = std::max(32, (int)(cwmax[g] * shrink)) & ~3;
+            int pitch_max = (cw_max + halo + 3 + 3) & ~3;
+            if ((pitch_max / 4) % 2 == 0) pitch_max += 4;
+            int ch_max = (int)(budget / (size_t)pitch_max) - halo;
+            ch_max = std::max(16, (int)(ch_max * shrink));
+            r.ncx = (p.key.cols + cw_max - 1) / cw_max;
+            r.cell_w = (((p.key.cols + r.ncx - 1) / r.ncx) + 3) & ~3;
+            r.ncy = (p.key.rows + ch_max - 1) / ch_max;
+            r.cell_h = (p.key.rows + r.ncy - 1) / r.ncy;
+            r.pitch = (r.cell_w + halo + 3 + 3) & ~3;
+            if ((r.pitch / 4) % 2 == 0) r.pitch += 4;  // odd dword pitch: consecutive rows start on different banks
+            r.rows = r.cell_h + halo;
+            if ((long long)r.ncx * r.ncy * p.max_frames >= 512 || (cw_max <= 32 && ch_max <= 16) || shrink < 0.05) break;
+            shrink *= 0.8;
+        }
+        if ((size_t)r.pitch * r.rows > budget) return false;
+        if ((long long)std::max(up, dn) * r.pitch + std::max(up, dn) > 32767) return false;  // packed int16 offsets
+        if ((size_t)r.pitch * r.rows + fixed + 2048 >= (1u << 18)) return false;  // pool entries hold an 18-bit LDS address
+        for (int j = k_lo; j < k; ++j) {  // queue entries hold a window's index within (rung, cell) in 16 bits
+            const long long ni = (r.cell_h + p.scales[j].step - 1) / p.scales[j].step + 1, nj = (r.cell_w + p.scales[j].step - 1) / p.scales[j].step + 1;
+            if (ni * nj > 65535) return false;
+        }
+        r.k_lo = k_lo;
+        r.k_hi = k;
+        r.halo_up = up;
+        r.pool_cap = pool_cap;
+        r.n_chunk_stages = n_cs;
+        r.t_pool = t_pool;
+        r.nh = nh;
+        r.wave_chunk = chunkg[g];
+        r.deep_cap = deepg[g];
+        for (int j = k_lo; j < k; ++j)
+            if (p.scales[j].s >= (1 << 14)) return false;
+        p.regions.push_back({r, fixed + (size_t)r.pitch * r.rows});
+    }
+    if (p.regions.empty()) return false;
+    const int kbig = p.regions.back().args.k_hi;
+    for (pigo_plan::TileClass &cls : p.classes) {
+        cls.v3_skip = 0;
+        for (uint32_t t = 0; t < cls.ntiles; ++t)
+            if ((int)p.tiles2[cls.tile0 + t].x < kbig) ++cls.v3_skip;  // tiles are stored in rung order within a class
+    }
+    return true;
 }
 
 int env_int(const char *name, int dflt)
@@ -627,6 +729,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     if (!p) return fail(PIGO_ERR_NOMEM, "out of memory");
     p->c = c;
     p->key = key;
+    p->max_frames = max_frames;  // (the region grid of variant 3 is sized for the plan's batch)
     p->rot = key.angle > 0.0;  // pigo.go:232
     if (p->rot) {
         const double a = key.angle > 1.0 ? 1.0 : key.angle;  // pigo.go:233-235
@@ -700,6 +803,22 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
             HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
         }
+        p->region_ok = build_region_groups(*p);
+        if (p->region_ok) {
+            // the region groups' offset tables: k_build_tabp with every rung's pitch set to its group's region pitch
+            std::vector<ScaleDesc> sreg(p->scales);
+            for (ScaleDesc &sd : sreg) sd.pitch = 0;
+            for (const pigo_plan::RegionGroup &g : p->regions)
+                for (int j = g.args.k_lo; j < g.args.k_hi; ++j) sreg[j].pitch = g.args.pitch;
+            DevBuf<ScaleDesc> d_sreg;
+            HIP_TRY(d_sreg.alloc(nscales));
+            HIP_TRY(hipMemcpy(d_sreg.p, sreg.data(), nscales * sizeof(ScaleDesc), hipMemcpyHostToDevice));
+            HIP_TRY(p->d_tabr.alloc(n));
+            k_build_tabp<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256>>>(c->d_codes.p, d_sreg.p, p->d_tabr.p, nscales, (int)c->ntrees, 0, 0, 0);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFuncSetAttribute((const void *)k_scan_region, hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 3072));
+        }
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
@@ -713,6 +832,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.tab = p->d_tab.p;
     a.tiles2 = p->d_tiles2.p;
     a.tabp = p->d_tabp.p;
+    a.tabr = p->d_tabr.p;
     a.codes = c->d_codes.p;
     a.late_waves = std::max(1, std::min(kLateWaves, env_int("PIGO_LATE_WAVES", kLateWaves)));
     a.qb_div = 2;  // per class, see build_tile_classes
@@ -743,7 +863,8 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.det_cap = det_cap;
     // variant 2 (LDS tiles, whole cascade per tile) for depth-6 cascades, variant 0 (monolithic lane-per-window kernel) for
     // everything else and as the overflow answer; variant 1 (the first head + tail design) exists in the debug build only
-    p->variant = (c->depth == 6 && c->ntrees > 0 && p->tile_ok) ? env_int("PIGO_SCAN_VARIANT", 2) : 0;
+    p->variant = (c->depth == 6 && c->ntrees > 0 && p->tile_ok) ? env_int("PIGO_SCAN_VARIANT", p->region_ok ? 3 : 2) : 0;
+    if (p->variant == 3 && !p->region_ok) p->variant = 2;
     if (p->variant == 2 && !p->tile_ok) p->variant = 0;
 #ifdef PIGO_DEBUG_BUILD
     build_stages(*p, env_int("PIGO_HEAD_STAGES", kMaxHeadStages));
@@ -751,19 +872,30 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
 #else
     if (p->variant == 1) p->variant = 0;
 #endif
-    if (p->variant < 0 || p->variant > 2) p->variant = 0;
+    if (p->variant < 0 || p->variant > 3) p->variant = 0;
     out = std::move(p);
     return PIGO_OK;
 }
 
 // variant 2, first half of a (chunk of a) batch: one k_scan_tile launch per tile class; `xcd_cap` = entries per XCD queue
 template <bool ROT, bool GUARD, class Mark>
-void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipStream_t s, Mark &mark)
+void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipStream_t s, Mark &mark, bool v3 = false)
 {
+    // variant 3: the region kernel scans the rungs of its scale groups, k_scan_tile only what lies beyond them
+    if (v3) {
+        for (const pigo_plan::RegionGroup &g : p.regions) {
+            ScanArgs ra = a;
+            ra.qcap = xcd_cap;
+            ra.reg = g.args;
+            mark(&g == &p.regions.front() ? "scan_region_small" : "scan_region_mid");
+            if constexpr (!ROT)
+                k_scan_region<<<(uint32_t)a.nframes * (uint32_t)(g.args.ncx * g.args.ncy), kRegThreads, g.dyn_lds, s>>>(ra);
+        }
+    }
     // fork: classes that gather from global memory go to the side stream when the plan also has LDS-tile classes
     bool has_lds = false, has_glb = false;
     for (const pigo_plan::TileClass &cls : p.classes)
-        if (cls.ntiles) (cls.lds ? has_lds : has_glb) = true;
+        if (cls.ntiles - (v3 ? cls.v3_skip : 0u)) (cls.lds ? has_lds : has_glb) = true;
     const bool fork = p.side && has_lds && has_glb && !p.profiling;
     const bool fork_all = fork && p.side_mode == 2;
     if (fork) {
@@ -774,7 +906,8 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
     }
     int lds_idx = 0;
     for (const pigo_plan::TileClass &cls : p.classes) {
-        if (cls.ntiles == 0) continue;
+        const uint32_t skip = v3 ? cls.v3_skip : 0u;
+        if (cls.ntiles == skip) continue;
         hipStream_t cs = (fork && !cls.lds) ? p.side : s;
         if (fork_all && cls.lds) {
             if (lds_idx > 0 && lds_idx <= 3) cs = p.side2[lds_idx - 1];
@@ -782,14 +915,14 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
         }
         ScanArgs ca = a;
         ca.qcap = xcd_cap;
-        ca.cls_tile0 = cls.tile0;
-        ca.cls_ntiles = cls.ntiles;
+        ca.cls_tile0 = cls.tile0 + skip;
+        ca.cls_ntiles = cls.ntiles - skip;
         ca.tw_log2 = cls.tw_log2;
         ca.th = cls.th;
         ca.nwin = cls.nwin;
         ca.tab_trees = cls.lds ? p.tab_lds : p.tab_glb;
         ca.qb_div = cls.qb_div;
-        const uint32_t grid = (uint32_t)a.nframes * cls.ntiles;
+        const uint32_t grid = (uint32_t)a.nframes * (cls.ntiles - skip);
         mark(cls.lds ? "scan_tile_lds" : "scan_tile_glb");
         const bool wide = p.tile_threads == 512;
         if constexpr (!ROT) {
@@ -858,13 +991,14 @@ template <bool ROT, bool GUARD, class Mark>
 void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t s, Mark &mark)
 {
     const uint32_t nb = (uint32_t)a.nframes * (uint32_t)a.ntiles;
-    if (variant == 2) {
+    if (variant == 2 || variant == 3) {
+        const bool v3 = variant == 3;
         const long long qtotal = p.qcap * (long long)p.max_frames;  // entries of d_queue
         const int want_chunks = p.pipe_chunks > 0 ? p.pipe_chunks : std::max(2, std::min(8, (a.nframes + 31) / 32));
         const int chunks = (p.tail_stream && !p.profiling && a.nframes >= 16 && a.deep_lo < a.ntrees) ? want_chunks : 1;
         if (chunks <= 1) {
             const uint32_t xcd_cap = (uint32_t)std::min<long long>(qtotal / 8, 0xffffffffLL);
-            launch_tiles<ROT, GUARD>(p, a, xcd_cap, s, mark);
+            launch_tiles<ROT, GUARD>(p, a, xcd_cap, s, mark, v3);
             launch_tail<ROT, GUARD>(p, a, xcd_cap, p.d_queue2.p, (uint32_t)p.qcap2, s, mark);
         } else {
             // Frames are independent, so the batch is cut into chunks (multiples of 8 frames: the XCD dealing) and the deep
@@ -886,7 +1020,7 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
                 ac.qcount = p.d_qcount.p + 16 * set;
                 if (used[set]) (void)hipStreamWaitEvent(s, p.ev_tail[set], 0);  // the tail of chunk c-2 is done with this set
                 (void)hipMemsetAsync(ac.qcount, 0, 16 * sizeof(uint32_t), s);
-                launch_tiles<ROT, GUARD>(p, ac, xcd_cap, s, mark);
+                launch_tiles<ROT, GUARD>(p, ac, xcd_cap, s, mark, v3);
                 (void)hipEventRecord(p.ev_tiles[set], s);
                 (void)hipStreamWaitEvent(p.tail_stream, p.ev_tiles[set], 0);
                 launch_tail<ROT, GUARD>(p, ac, xcd_cap, p.d_queue2.p + (size_t)set * half2, (uint32_t)half2, p.tail_stream, mark);
@@ -1002,7 +1136,7 @@ extern "C" pigo_status pigo_plan_info(const pigo_plan *p, pigo_plan_info_t *info
     info->n_scales = (int32_t)p->scales.size();
     info->n_ladder = p->n_ladder;
     info->tiles_per_frame = (int32_t)p->tiles.size();
-    info->n_head_trees = p->variant == 2 ? p->args.nh_lds : p->args.nh;
+    info->n_head_trees = p->variant >= 2 ? p->args.nh_lds : p->args.nh;
     info->variant = p->variant;
     info->max_frames = p->max_frames;
     info->det_cap = p->det_cap;
@@ -1014,7 +1148,8 @@ extern "C" pigo_status pigo_plan_info(const pigo_plan *p, pigo_plan_info_t *info
 extern "C" pigo_status pigo_plan_set_variant(pigo_plan *p, int variant)
 {
     if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
-    if (variant < 0 || variant > 2) return fail(PIGO_ERR_PARAM, "variant must be 0, 1 or 2");
+    if (variant < 0 || variant > 3) return fail(PIGO_ERR_PARAM, "variant must be 0, 1, 2 or 3");
+    if (variant == 3 && !p->region_ok) return fail(PIGO_ERR_PARAM, "variant 3 not available for this plan (rotated scan, stride not a multiple of 4, ...)");
 #ifndef PIGO_DEBUG_BUILD
     if (variant == 1) return fail(PIGO_ERR_PARAM, "variant 1 exists in the debug build only (python -m pigo_amd.build --debug)");
 #endif
@@ -1128,7 +1263,7 @@ extern "C" pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n)
     *n = 0;
     if (p->last_nframes == 0) return PIGO_OK;
     HIP_TRY(hipMemcpy(h.data(), p->d_qcount.p, (size_t)p->last_nframes * 4, hipMemcpyDeviceToHost));
-    if (p->variant == 2) {
+    if (p->variant >= 2) {
         uint32_t h8[8] = {0};
         HIP_TRY(hipMemcpy(h8, p->d_qcount.p, sizeof h8, hipMemcpyDeviceToHost));
         *n = 0;

@@ -18,9 +18,10 @@ pytestmark = pytest.mark.gpu
 Q_TOL_CONTRACT = 1e-5  # north_star: "within 1e-5 on the float q score"
 Q_TOL_RAW = 0.0        # design target: bit-exact
 
-# scan implementations of the release library: 2 = LDS tiles (default), 0 = monolithic fallback.  Variant 1 (the first
-# head + tail design) is compiled into the debug build only (python -m pigo_amd.build --debug; PIGO_HIP_LIB selects it).
-VARIANTS = [2, 0] + ([1] if "debug" in core.library_path() else [])
+# scan implementations of the release library: 3 = LDS regions (default where eligible), 2 = LDS tiles, 0 = monolithic
+# fallback.  Variant 1 (the first head + tail design) is compiled into the debug build only (python -m pigo_amd.build --debug;
+# PIGO_HIP_LIB selects it).
+VARIANTS = [3, 2, 0] + ([1] if "debug" in core.library_path() else [])
 
 
 def _cp(img, rows, cols, dim, mn, mx, shift, scale):
@@ -297,6 +298,7 @@ def test_queue_overflow_falls_back_to_monolithic(orc, monkeypatch):
     from pigo_amd import batch
     monkeypatch.setenv("PIGO_QUEUE_DIV", "100000000")  # queue capacity = the floor ...
     monkeypatch.setenv("PIGO_QUEUE_MIN", "8")           # ... of 8 entries per frame: the per-XCD survivor queues hold 2 entries each
+    monkeypatch.setenv("PIGO_SCAN_VARIANT", "2")        # the survivor queue belongs to k_scan_tile / k_tail_deep (variant 3 keeps them for scales > 135 only)
     fresh = core.NewPigo(0).Unpack(synth.facefinder_bytes())
     rows, cols = 540, 960
     f = synth.make_frames("faces", 2, rows, cols, seed=5)
@@ -365,7 +367,7 @@ def test_4k_config5_variants_agree_and_match_oracle(pg, orc):
         torch.cuda.synchronize()
         plan.status()  # no queue overflow, i.e. no silent trip through the monolithic fallback, on the step-1 scales
         res[variant] = batch.dets_to_numpy(dets, counts, 0)
-    for v in VARIANTS[1:]:
+    for v in VARIANTS:
         assert_same_dets(res[v], res[2], f"4K v{v} vs v2", Q_TOL_RAW)
     want = orc.run_cascade(f[0], 2160, 3840, 3840, 20, 2000, 0.05, 1.05, 0.0)  # ~15 s of CPU
     assert_same_dets(res[2], want, "4K vs oracle", Q_TOL_RAW)
