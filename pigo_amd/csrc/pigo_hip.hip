@@ -150,7 +150,11 @@ struct pigo_plan {
     };
     std::vector<RegionGroup> regions;
     bool region_ok = false;
+    bool sparse_mode = true;             // variant 3: rungs beyond the region groups by k_scan_sparse (else k_scan_tile + k_tail_deep)
     DevBuf<uint32_t> d_tabr;
+    // variant 3, rungs beyond the region groups: k_scan_sparse, one wave per 64 consecutive windows {rung, first window}
+    std::vector<uint2> sparse_groups;
+    DevBuf<uint2> d_sparse;
     DevBuf<uint32_t> d_tabp;
     bool tile_ok = false;
     int tab_lds = 0, tab_glb = 0;        // LDS table capacity (trees) of the LDS-pixel / global-pixel classes
@@ -677,6 +681,11 @@ bool build_region_groups(pigo_plan &p)
     }
     if (p.regions.empty()) return false;
     const int kbig = p.regions.back().args.k_hi;
+    p.sparse_groups.clear();
+    for (int j = kbig; j < nscales; ++j) {
+        const long long nw = (long long)p.scales[j].nr * p.scales[j].nc;
+        for (long long f0 = 0; f0 < nw; f0 += 64) p.sparse_groups.push_back(make_uint2((unsigned)j, (unsigned)f0));
+    }
     for (pigo_plan::TileClass &cls : p.classes) {
         cls.v3_skip = 0;
         for (uint32_t t = 0; t < cls.ntiles; ++t)
@@ -804,6 +813,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
             HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
         }
         p->region_ok = build_region_groups(*p);
+        p->sparse_mode = env_int("PIGO_SPARSE", 0) != 0;  // (measured: 10x slower than the tile classes -- uncompacted byte gathers; kept as an A/B switch)
         if (p->region_ok) {
             // the region groups' offset tables: k_build_tabp with every rung's pitch set to its group's region pitch
             std::vector<ScaleDesc> sreg(p->scales);
@@ -818,6 +828,10 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipDeviceSynchronize());
             HIP_TRY(hipFuncSetAttribute((const void *)k_scan_region, hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 3072));
+            if (!p->sparse_groups.empty()) {
+                HIP_TRY(p->d_sparse.alloc(p->sparse_groups.size()));
+                HIP_TRY(hipMemcpy(p->d_sparse.p, p->sparse_groups.data(), p->sparse_groups.size() * sizeof(uint2), hipMemcpyHostToDevice));
+            }
         }
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
@@ -879,10 +893,11 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
 
 // variant 2, first half of a (chunk of a) batch: one k_scan_tile launch per tile class; `xcd_cap` = entries per XCD queue
 template <bool ROT, bool GUARD, class Mark>
-void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipStream_t s, Mark &mark, bool v3 = false)
+void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipStream_t s, Mark &mark, bool v3 = false, int what = 3)
 {
     // variant 3: the region kernel scans the rungs of its scale groups, k_scan_tile only what lies beyond them
-    if (v3) {
+    // (what & 1: the region / sparse launches, what & 2: the tile classes)
+    if (v3 && (what & 1)) {
         for (const pigo_plan::RegionGroup &g : p.regions) {
             ScanArgs ra = a;
             ra.qcap = xcd_cap;
@@ -891,7 +906,16 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
             if constexpr (!ROT)
                 k_scan_region<<<(uint32_t)a.nframes * (uint32_t)(g.args.ncx * g.args.ncy), kRegThreads, g.dyn_lds, s>>>(ra);
         }
+        if (p.sparse_mode && !p.sparse_groups.empty()) {
+            ScanArgs sa = a;
+            sa.reg = p.regions.front().args;  // (nh)
+            const uint32_t ng = (uint32_t)p.sparse_groups.size();
+            mark("scan_sparse");
+            k_scan_sparse<<<(uint32_t)a.nframes * ((ng + 3u) / 4u), 256, 0, s>>>(sa, p.d_sparse.p, ng);
+        }
+        if (p.sparse_mode) return;  // every window of the frame is covered: no tile classes
     }
+    if (!(what & 2)) return;
     // fork: classes that gather from global memory go to the side stream when the plan also has LDS-tile classes
     bool has_lds = false, has_glb = false;
     for (const pigo_plan::TileClass &cls : p.classes)
@@ -995,8 +1019,28 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
         const bool v3 = variant == 3;
         const long long qtotal = p.qcap * (long long)p.max_frames;  // entries of d_queue
         const int want_chunks = p.pipe_chunks > 0 ? p.pipe_chunks : std::max(2, std::min(8, (a.nframes + 31) / 32));
-        const int chunks = (p.tail_stream && !p.profiling && a.nframes >= 16 && a.deep_lo < a.ntrees) ? want_chunks : 1;
-        if (chunks <= 1) {
+        // (variant 3 with the sparse kernel finishes every window inside its own launches: nothing to overlap, one chunk)
+        const int chunks = (p.tail_stream && !p.profiling && a.nframes >= 16 && a.deep_lo < a.ntrees && !v3) ? want_chunks : 1;
+        if (v3 && !p.sparse_mode && p.side && !p.profiling && a.deep_lo < a.ntrees) {
+            // Variant 3: the region launches (LDS-bound, they keep every window of their scales to themselves) on `s`, the tile
+            // classes of the big scales and their deep tail (vector-memory / latency bound) next to them on the side stream.
+            // Two queue sets: A for the tile classes, B for the (rare) spill of the regions' deep lists.
+            const long long half = qtotal / 2, half2 = p.qcap2 / 2;
+            const uint32_t xcd_cap = (uint32_t)std::min<long long>(half / 8, 0xffffffffLL);
+            (void)hipEventRecord(p.ev_fork, s);
+            (void)hipStreamWaitEvent(p.side, p.ev_fork, 0);
+            ScanArgs aa = a, ab = a;
+            aa.queue = p.d_queue.p;
+            aa.qcount = p.d_qcount.p;
+            ab.queue = p.d_queue.p + half;
+            ab.qcount = p.d_qcount.p + 16;
+            launch_tiles<ROT, GUARD>(p, aa, xcd_cap, p.side, mark, true, 2);
+            launch_tail<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, p.side, mark);
+            (void)hipEventRecord(p.ev_join, p.side);
+            launch_tiles<ROT, GUARD>(p, ab, xcd_cap, s, mark, true, 1);
+            launch_tail<ROT, GUARD>(p, ab, xcd_cap, p.d_queue2.p + half2, (uint32_t)half2, s, mark);
+            (void)hipStreamWaitEvent(s, p.ev_join, 0);
+        } else if (chunks <= 1) {
             const uint32_t xcd_cap = (uint32_t)std::min<long long>(qtotal / 8, 0xffffffffLL);
             launch_tiles<ROT, GUARD>(p, a, xcd_cap, s, mark, v3);
             launch_tail<ROT, GUARD>(p, a, xcd_cap, p.d_queue2.p, (uint32_t)p.qcap2, s, mark);
@@ -1068,7 +1112,7 @@ pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame
     a.nframes = nframes;
     a.counts = d_counts;
     a.tail_wgs = std::max(8, std::min(256, 2048 / nframes));
-    if (variant >= 1) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)std::max(nframes, 16) * 4, s));
+    if (variant >= 1) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)std::max(nframes, 32) * 4, s));
 
     size_t ev = 0;
     static const bool sync_debug = env_int("PIGO_SYNC_DEBUG", 0) != 0;  // debugging aid: synchronise and report before every kernel
