@@ -96,8 +96,12 @@ struct pigo_cascade {
     std::vector<float> thr;              // treeThreshold [ntrees]
     DevBuf<int8_t> d_codes;
     DevBuf<float> d_leaf, d_thr;
-    std::mutex mu;                       // serialises the single-frame entry points and the plan cache
-    std::list<std::unique_ptr<pigo_plan>> cache;   // most recently used first
+    std::mutex mu;                       // guards the slot list below and pigo_cluster_detections' scratch
+    // RunCascade slots: everything one call needs (plan, device + pinned host buffers, a stream, the captured graph of
+    // "upload, scan, download").  A call takes a free slot with its parameters (or makes one), so goroutines calling RunCascade on
+    // one *Pigo concurrently -- the reference is re-entrant, examples/web/main.go:71,141 -- run next to each other on the GPU.
+    struct RunSlot;
+    std::list<std::unique_ptr<RunSlot>> slots;   // most recently used first
     // scratch for pigo_run_cascade / pigo_cluster_detections
     DevBuf<uint8_t> d_frame;
     DevBuf<pigo_det> d_dets, d_sorted, d_clusters;
@@ -113,6 +117,22 @@ struct PlanKey {
         return rows == o.rows && cols == o.cols && dim == o.dim && min_size == o.min_size && max_size == o.max_size &&
                shift == o.shift && scale == o.scale && angle == o.angle;
     }
+};
+
+struct pigo_cascade::RunSlot {
+    PlanKey key{};
+    std::unique_ptr<pigo_plan> plan;
+    bool busy = false;
+    hipStream_t stream = nullptr;
+    DevBuf<uint8_t> d_frame;
+    DevBuf<pigo_det> d_dets;
+    DevBuf<int32_t> d_count;
+    uint8_t *h_frame = nullptr;          // pinned staging: the caller's pixels go through it (cgo memory is pageable)
+    pigo_det *h_dets = nullptr;
+    int32_t *h_small = nullptr;          // [0] detection count, [1..4] the plan's status flags
+    size_t fbytes = 0;
+    hipGraphExec_t exec = nullptr;       // H2D + pigo_plan_run + D2H of count, flags and detections
+    ~RunSlot();
 };
 
 struct pigo_plan {
@@ -190,6 +210,18 @@ struct pigo_plan {
     hipEvent_t ev_join2[3] = {nullptr, nullptr, nullptr};
     int side_mode = 1;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t grp_stream = nullptr;    // variant 3, small batches: the second region group runs next to the first
+    hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
+    // small batches: the launch sequence of pigo_plan_run is captured once per (buffers, batch) and replayed as a hipGraph
+    struct GraphCache {
+        const void *frames = nullptr;
+        size_t stride = 0;
+        int nframes = 0, variant = -1;
+        void *dets = nullptr, *counts = nullptr;
+        hipGraphExec_t exec = nullptr;
+    } gc;
+    hipStream_t cap_stream = nullptr;
+    int graph_max_frames = 0;            // batches up to this size are replayed from a graph (0 = never)
     // chunked pipeline: the deep tail of chunk c runs on `tail_stream` next to the tile kernels of chunk c+1 (two queue sets)
     int pipe_chunks = 0;                 // 0 = automatic
     hipStream_t tail_stream = nullptr;
@@ -201,6 +233,11 @@ struct pigo_plan {
             if (ev_tail[i]) (void)hipEventDestroy(ev_tail[i]);
         }
         if (tail_stream) (void)hipStreamDestroy(tail_stream);
+        if (gc.exec) (void)hipGraphExecDestroy(gc.exec);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        if (grp_stream) (void)hipStreamDestroy(grp_stream);
+        if (ev_gfork) (void)hipEventDestroy(ev_gfork);
+        if (ev_gjoin) (void)hipEventDestroy(ev_gjoin);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -216,6 +253,16 @@ struct pigo_plan {
                d_mq.bytes();
     }
 };
+
+pigo_cascade::RunSlot::~RunSlot()
+{
+    if (exec) (void)hipGraphExecDestroy(exec);
+    plan.reset();
+    if (stream) (void)hipStreamDestroy(stream);
+    if (h_frame) (void)hipHostFree(h_frame);
+    if (h_dets) (void)hipHostFree(h_dets);
+    if (h_small) (void)hipHostFree(h_small);
+}
 
 extern "C" const char *pigo_last_error(void) { return g_last_error.c_str(); }
 
@@ -656,7 +703,7 @@ bool build_region_groups(pigo_plan &p)
             r.pitch = (r.cell_w + halo + 3 + 3) & ~3;
             if ((r.pitch / 4) % 2 == 0) r.pitch += 4;  // odd dword pitch: consecutive rows start on different banks
             r.rows = r.cell_h + halo;
-            if ((long long)r.ncx * r.ncy * p.max_frames >= 512 || (cw_max <= 32 && ch_max <= 16) || shrink < 0.05) break;
+            if ((long long)r.ncx * r.ncy * p.max_frames >= env_int("PIGO_REG_MIN_REGIONS", 256) || (cw_max <= 32 && ch_max <= 16) || shrink < 0.05) break;
             shrink *= 0.8;
         }
         if ((size_t)r.pitch * r.rows > budget) return false;
@@ -812,6 +859,13 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
             HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
         }
+        HIP_TRY(hipStreamCreateWithFlags(&p->grp_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_gfork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_gjoin, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+        // graph replay of small batches: off by default -- on ROCm 7.2 a replayed graph of this sequence is no faster than the
+        // eager launches (profiles/r02_experiments.md); PIGO_GRAPH_FRAMES=n turns it on for batches of up to n frames
+        p->graph_max_frames = std::max(0, env_int("PIGO_GRAPH_FRAMES", 0));
         p->region_ok = build_region_groups(*p);
         p->sparse_mode = env_int("PIGO_SPARSE", 0) != 0;  // (measured: 10x slower than the tile classes -- uncompacted byte gathers; kept as an A/B switch)
         if (p->region_ok) {
@@ -877,7 +931,9 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.det_cap = det_cap;
     // variant 2 (LDS tiles, whole cascade per tile) for depth-6 cascades, variant 0 (monolithic lane-per-window kernel) for
     // everything else and as the overflow answer; variant 1 (the first head + tail design) exists in the debug build only
-    p->variant = (c->depth == 6 && c->ntrees > 0 && p->tile_ok) ? env_int("PIGO_SCAN_VARIANT", p->region_ok ? 3 : 2) : 0;
+    // variant 3 (LDS regions) for batches; a plan for a handful of frames cannot fill 256 CUs with 1024-thread region workgroups
+    // and is served faster by the tile kernel (measured: one 1080p frame 0.20 ms vs 0.29 ms, profiles/r02_experiments.md)
+    p->variant = (c->depth == 6 && c->ntrees > 0 && p->tile_ok) ? env_int("PIGO_SCAN_VARIANT", (p->region_ok && max_frames >= 8) ? 3 : 2) : 0;
     if (p->variant == 3 && !p->region_ok) p->variant = 2;
     if (p->variant == 2 && !p->tile_ok) p->variant = 0;
 #ifdef PIGO_DEBUG_BUILD
@@ -898,13 +954,25 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
     // variant 3: the region kernel scans the rungs of its scale groups, k_scan_tile only what lies beyond them
     // (what & 1: the region / sparse launches, what & 2: the tile classes)
     if (v3 && (what & 1)) {
+        // a small batch cannot fill the chip with one group's regions: the groups then run next to each other
+        const bool par = p.grp_stream && !p.profiling && a.nframes < 8 && p.regions.size() > 1;
         for (const pigo_plan::RegionGroup &g : p.regions) {
+            const bool first = &g == &p.regions.front();
+            hipStream_t gs = (par && !first) ? p.grp_stream : s;
+            if (par && !first) {
+                (void)hipEventRecord(p.ev_gfork, s);
+                (void)hipStreamWaitEvent(gs, p.ev_gfork, 0);
+            }
             ScanArgs ra = a;
             ra.qcap = xcd_cap;
             ra.reg = g.args;
-            mark(&g == &p.regions.front() ? "scan_region_small" : "scan_region_mid");
+            mark(first ? "scan_region_small" : "scan_region_mid");
             if constexpr (!ROT)
-                k_scan_region<<<(uint32_t)a.nframes * (uint32_t)(g.args.ncx * g.args.ncy), kRegThreads, g.dyn_lds, s>>>(ra);
+                k_scan_region<<<(uint32_t)a.nframes * (uint32_t)(g.args.ncx * g.args.ncy), kRegThreads, g.dyn_lds, gs>>>(ra);
+            if (par && !first) {
+                (void)hipEventRecord(p.ev_gjoin, gs);
+                (void)hipStreamWaitEvent(s, p.ev_gjoin, 0);
+            }
         }
         if (p.sparse_mode && !p.sparse_groups.empty()) {
             ScanArgs sa = a;
@@ -920,7 +988,8 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
     bool has_lds = false, has_glb = false;
     for (const pigo_plan::TileClass &cls : p.classes)
         if (cls.ntiles - (v3 ? cls.v3_skip : 0u)) (cls.lds ? has_lds : has_glb) = true;
-    const bool fork = p.side && has_lds && has_glb && !p.profiling;
+    // (a small batch is launch-bound: every fork / join costs more than the overlap buys -- one stream then)
+    const bool fork = p.side && has_lds && has_glb && !p.profiling && a.nframes >= 8;
     const bool fork_all = fork && p.side_mode == 2;
     if (fork) {
         (void)hipEventRecord(p.ev_fork, s);
@@ -1208,7 +1277,52 @@ extern "C" pigo_status pigo_plan_run(pigo_plan *p, const uint8_t *d_frames, size
 {
     if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
     std::lock_guard<std::mutex> lock(p->mu);  // a plan owns one workspace: launches on it are serialised
-    return plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, (hipStream_t)stream, p->variant);
+    hipStream_t s = (hipStream_t)stream;
+    if (nframes < 1 || nframes > p->graph_max_frames || p->profiling || !p->cap_stream)
+        return plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, s, p->variant);
+    // Small batch: ~10 dependent launches, memsets and stream joins cost more host time than GPU time.  The sequence only
+    // depends on the buffers, so it is captured once (on an internal stream: the caller's may be the legacy default stream,
+    // which cannot be captured) and replayed on the caller's stream as one graph launch.
+    pigo_plan::GraphCache &gc = p->gc;
+    if (!(gc.exec && gc.frames == d_frames && gc.stride == frame_stride && gc.nframes == nframes && gc.dets == d_dets && gc.counts == d_counts &&
+          gc.variant == p->variant)) {
+        HIP_TRY(hipSetDevice(p->c->device));
+        if (gc.exec) {
+            (void)hipGraphExecDestroy(gc.exec);
+            gc.exec = nullptr;
+        }
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
+        const pigo_status st = plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, p->cap_stream, p->variant);
+        const hipError_t e = hipStreamEndCapture(p->cap_stream, &graph);
+        if (st != PIGO_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return st;
+        }
+        if (e != hipSuccess || !graph) {  // capture not possible here: run the plain way
+            (void)hipGetLastError();
+            p->graph_max_frames = 0;
+            return plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, s, p->variant);
+        }
+        const hipError_t ei = hipGraphInstantiate(&gc.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) {
+            gc.exec = nullptr;
+            (void)hipGetLastError();
+            p->graph_max_frames = 0;
+            return plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, s, p->variant);
+        }
+        gc.frames = d_frames;
+        gc.stride = frame_stride;
+        gc.nframes = nframes;
+        gc.dets = d_dets;
+        gc.counts = d_counts;
+        gc.variant = p->variant;
+    }
+    p->last_nframes = nframes;
+    p->n_timed = 0;
+    HIP_TRY(hipGraphLaunch(gc.exec, s));
+    return PIGO_OK;
 }
 
 extern "C" pigo_status pigo_plan_status(pigo_plan *p)
@@ -1389,6 +1503,23 @@ extern "C" pigo_status pigo_cluster_detections(pigo_cascade *c, pigo_det *dets, 
 
 // ---- RunCascade (one frame, host memory) ----------------------------------------------------------------------------------
 
+namespace {
+
+// enqueue one RunCascade on the slot's stream: upload, scan, download of the count, the status flags and the detections
+pigo_status slot_enqueue(pigo_cascade::RunSlot &sl)
+{
+    pigo_plan *p = sl.plan.get();
+    HIP_TRY(hipMemcpyAsync(sl.d_frame.p, sl.h_frame, sl.fbytes, hipMemcpyHostToDevice, sl.stream));
+    pigo_status st = plan_run_variant(p, sl.d_frame.p, sl.fbytes, 1, sl.d_dets.p, sl.d_count.p, sl.stream, p->variant);
+    if (st != PIGO_OK) return st;
+    HIP_TRY(hipMemcpyAsync(sl.h_small, sl.d_count.p, 4, hipMemcpyDeviceToHost, sl.stream));
+    HIP_TRY(hipMemcpyAsync(sl.h_small + 1, p->d_flags.p, 16, hipMemcpyDeviceToHost, sl.stream));
+    HIP_TRY(hipMemcpyAsync(sl.h_dets, sl.d_dets.p, (size_t)p->det_cap * sizeof(pigo_det), hipMemcpyDeviceToHost, sl.stream));
+    return PIGO_OK;
+}
+
+}  // namespace
+
 extern "C" pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, size_t npixels, int rows, int cols, int dim, int min_size,
                                         int max_size, double shift_factor, double scale_factor, double angle, pigo_det *out, int cap,
                                         int *n_out)
@@ -1399,45 +1530,100 @@ extern "C" pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, 
     if (cap < 0 || (cap > 0 && !out)) return fail(PIGO_ERR_PARAM, "bad output buffer");
     if (rows >= 1 && dim >= 1 && npixels < (size_t)rows * (size_t)dim)
         return fail(PIGO_ERR_PARAM, "len(pixels)=%zu < rows*dim=%zu", npixels, (size_t)rows * (size_t)dim);
-    std::lock_guard<std::mutex> lock(c->mu);
-    PlanKey key{rows, cols, dim, min_size, max_size, shift_factor, scale_factor, angle};
-    pigo_plan *p = nullptr;
-    for (auto it = c->cache.begin(); it != c->cache.end(); ++it) {
-        if ((*it)->key == key) {
-            c->cache.splice(c->cache.begin(), c->cache, it);
-            p = c->cache.front().get();
-            break;
-        }
-    }
+    const PlanKey key{rows, cols, dim, min_size, max_size, shift_factor, scale_factor, angle};
+    const size_t fbytes = (size_t)rows * (size_t)dim;
     int det_cap = std::max(cap, 4096);
+    HIP_TRY(hipSetDevice(c->device));
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (!p || p->det_cap < det_cap) {
-            if (p) c->cache.pop_front();
-            std::unique_ptr<pigo_plan> np;
-            pigo_status st = plan_build(c, key, 1, det_cap, np);
-            if (st != PIGO_OK) return st;
-            c->cache.push_front(std::move(np));
-            while (c->cache.size() > 4) c->cache.pop_back();
-            p = c->cache.front().get();
+        // ---- take a free slot with these parameters, or build one (the list is the only shared state) ----
+        pigo_cascade::RunSlot *sl = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(c->mu);
+            for (auto it = c->slots.begin(); it != c->slots.end(); ++it) {
+                if (!(*it)->busy && (*it)->key == key && (*it)->plan->det_cap >= det_cap) {
+                    c->slots.splice(c->slots.begin(), c->slots, it);
+                    sl = c->slots.front().get();
+                    sl->busy = true;
+                    break;
+                }
+            }
         }
-        HIP_TRY(hipSetDevice(c->device));
-        const size_t fbytes = (size_t)rows * (size_t)dim;
-        if (c->d_frame.n < fbytes) HIP_TRY(c->d_frame.alloc(fbytes));
-        if (c->d_dets.n < (size_t)p->det_cap) HIP_TRY(c->d_dets.alloc(p->det_cap));
-        if (c->d_small.n < 4) HIP_TRY(c->d_small.alloc(4));
-        HIP_TRY(hipMemcpy(c->d_frame.p, pixels, fbytes, hipMemcpyHostToDevice));
-        pigo_status st = pigo_plan_run_sync(p, c->d_frame.p, fbytes, 1, c->d_dets.p, c->d_small.p, nullptr);
-        if (st == PIGO_ERR_CAPACITY && p->last_flags[2] && !p->last_flags[0]) st = PIGO_OK;  // det_cap overflow: grown below
+        if (!sl) {
+            std::unique_ptr<pigo_cascade::RunSlot> ns(new (std::nothrow) pigo_cascade::RunSlot);
+            if (!ns) return fail(PIGO_ERR_NOMEM, "out of memory");
+            ns->key = key;
+            ns->fbytes = fbytes;
+            pigo_status st = plan_build(c, key, 1, det_cap, ns->plan);
+            if (st != PIGO_OK) return st;
+            HIP_TRY(hipStreamCreateWithFlags(&ns->stream, hipStreamNonBlocking));
+            HIP_TRY(ns->d_frame.alloc(fbytes));
+            HIP_TRY(ns->d_dets.alloc(det_cap));
+            HIP_TRY(ns->d_count.alloc(4));
+            HIP_TRY(hipHostMalloc((void **)&ns->h_frame, std::max<size_t>(fbytes, 16), hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void **)&ns->h_dets, (size_t)det_cap * sizeof(pigo_det), hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void **)&ns->h_small, 32, hipHostMallocDefault));
+            ns->busy = true;
+            if (env_int("PIGO_GRAPH_FRAMES", 0) >= 1) {  // capture the call once; without a graph the slot enqueues it every time
+                hipGraph_t graph = nullptr;
+                if (hipStreamBeginCapture(ns->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    const pigo_status cs = slot_enqueue(*ns);
+                    const hipError_t e = hipStreamEndCapture(ns->stream, &graph);
+                    if (cs == PIGO_OK && e == hipSuccess && graph && hipGraphInstantiate(&ns->exec, graph, nullptr, nullptr, 0) != hipSuccess) ns->exec = nullptr;
+                    if (graph) (void)hipGraphDestroy(graph);
+                    if (cs != PIGO_OK) return cs;
+                }
+                (void)hipGetLastError();
+            }
+            std::lock_guard<std::mutex> lock(c->mu);
+            c->slots.push_front(std::move(ns));
+            sl = c->slots.front().get();
+            // keep at most 8 idle slots
+            size_t idle = 0;
+            for (auto it = c->slots.begin(); it != c->slots.end();) {
+                if (!(*it)->busy && ++idle > 8)
+                    it = c->slots.erase(it);
+                else
+                    ++it;
+            }
+        }
+        struct Release {
+            pigo_cascade *c;
+            pigo_cascade::RunSlot *sl;
+            ~Release()
+            {
+                std::lock_guard<std::mutex> lock(c->mu);
+                sl->busy = false;
+            }
+        } release{c, sl};
+        pigo_plan *p = sl->plan.get();
+        memcpy(sl->h_frame, pixels, fbytes);
+        pigo_status st = PIGO_OK;
+        if (sl->exec)
+            HIP_TRY(hipGraphLaunch(sl->exec, sl->stream));
+        else
+            st = slot_enqueue(*sl);
         if (st != PIGO_OK) return st;
-        int32_t n = 0;
-        HIP_TRY(hipMemcpy(&n, c->d_small.p, 4, hipMemcpyDeviceToHost));
-        if (n > p->det_cap) {  // internal buffer too small: grow once and rescan
+        HIP_TRY(hipStreamSynchronize(sl->stream));
+        int32_t n = sl->h_small[0];
+        const int32_t fl_queue = sl->h_small[1], fl_panic = sl->h_small[2], fl_dets = sl->h_small[3];
+        if (fl_queue || fl_panic || fl_dets) HIP_TRY(hipMemsetAsync(p->d_flags.p, 0, 16, sl->stream));
+        if (fl_panic) return fail(PIGO_ERR_PANIC, "the reference would panic: pixel index out of range in classifyRotatedRegion (pigo.go:167-179)");
+        if (fl_queue) {  // pathological frame: more survivors than a queue holds -- the monolithic kernel has no queue
+            st = plan_run_variant(p, sl->d_frame.p, fbytes, 1, sl->d_dets.p, sl->d_count.p, sl->stream, 0);
+            if (st != PIGO_OK) return st;
+            HIP_TRY(hipMemcpyAsync(sl->h_small, sl->d_count.p, 4, hipMemcpyDeviceToHost, sl->stream));
+            HIP_TRY(hipMemcpyAsync(sl->h_dets, sl->d_dets.p, (size_t)p->det_cap * sizeof(pigo_det), hipMemcpyDeviceToHost, sl->stream));
+            HIP_TRY(hipStreamSynchronize(sl->stream));
+            HIP_TRY(hipMemsetAsync(p->d_flags.p, 0, 16, sl->stream));
+            n = sl->h_small[0];
+        }
+        if (n > p->det_cap) {  // internal buffer too small: a bigger slot, and rescan
             det_cap = n;
             continue;
         }
         if (n_out) *n_out = n;
         if (n > cap) return fail(PIGO_ERR_CAPACITY, "RunCascade: %d detections, capacity %d", n, cap);
-        if (n > 0) HIP_TRY(hipMemcpy(out, c->d_dets.p, (size_t)n * sizeof(pigo_det), hipMemcpyDeviceToHost));
+        if (n > 0) memcpy(out, sl->h_dets, (size_t)n * sizeof(pigo_det));
         return PIGO_OK;
     }
     return fail(PIGO_ERR_CAPACITY, "RunCascade: detection count kept growing");

@@ -470,3 +470,66 @@ def test_sharded_entry_point_world1_matches_plain_path(pg, orc):
 
 def batch_lists_to_host(lists, n):
     return lists[:n].cpu().numpy().view(core.DET_DTYPE).reshape(n, lists.shape[1])
+
+
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_run_cascade_is_reentrant_four_threads_one_handle(orc, graph, monkeypatch):
+    """The reference's RunCascade is re-entrant (examples/web/main.go:71,141 share one *Pigo between request handlers): four
+    host threads hammer ONE handle with different frames and parameters; every result must be the oracle's.  (Each call
+    takes its own slot -- plan, buffers, stream, captured graph -- so the calls overlap on the GPU instead of queueing.)"""
+    import threading
+    monkeypatch.setenv("PIGO_GRAPH_FRAMES", graph)  # with and without the captured upload-scan-download graph per slot
+    pg = core.NewPigo(0).Unpack(synth.facefinder_bytes())
+    jobs = []
+    for k in range(4):
+        rows, cols = (270, 480) if k % 2 == 0 else (400, 320)
+        img = synth.syn_faces(rows, cols, seed=40 + k) if k % 2 == 0 else synth.sample_gray()
+        shift = 0.1 if k < 2 else 0.2
+        jobs.append((img, rows, cols, shift, orc.run_cascade(img, rows, cols, cols, 20, 1000, shift, 1.1, 0.0)))
+    errors = []
+
+    def work(k):
+        img, rows, cols, shift, want = jobs[k]
+        try:
+            for rep in range(12):
+                got = pg.RunCascade(_cp(img, rows, cols, cols, 20, 1000, shift, 1.1), 0.0)
+                assert_same_dets(got, want, f"thread {k} rep {rep}", Q_TOL_RAW)
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    # two threads, SAME parameters: two slots of one key
+    errors.clear()
+    th = [threading.Thread(target=work, args=(0,)) for _ in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+
+
+def test_small_batch_graph_replay_matches_and_survives_buffer_changes(pg, orc, monkeypatch):
+    """pigo_plan_run replays a captured graph for small batches; new buffers or a new batch size must re-capture, and the
+    results must not depend on whether the launch sequence was replayed or issued."""
+    import torch
+    from pigo_amd import batch
+    rows, cols = 270, 480
+    frames = synth.make_frames("faces", 3, rows, cols, seed=9)
+    want = [orc.run_cascade(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1, 0.0) for f in range(3)]
+    d_frames = torch.from_numpy(frames).cuda()
+    monkeypatch.setenv("PIGO_GRAPH_FRAMES", "4")  # (read at plan creation; off by default)
+    plan = batch.ScanPlan(pg, rows, cols, max_frames=3, det_cap=512)
+    for n in (1, 3, 2, 3):
+        dets, counts = plan.alloc_outputs(n)  # fresh buffers every round: the cached graph must not be reused blindly
+        for rep in range(3):
+            plan.run(d_frames[:n], dets, counts)
+        torch.cuda.synchronize()
+        plan.status()
+        got = batch.dets_to_numpy(dets, counts)
+        for f in range(n):
+            assert_same_dets(got[f], want[f], f"graph replay n={n} frame {f}", Q_TOL_RAW)
