@@ -509,14 +509,15 @@ def main():
         # read every frame once), variant 1 k_scan_head (+ tail), variant 0 k_scan_mono.
         scan_names = [k for k in ktimes if k.startswith("scan_") or k.startswith("tail_")]
         scan_ms = sum(ktimes[k] for k in scan_names)
-        dom = {2: "scan_tile+tail_deep", 1: "scan_head+scan_tail", 0: "scan_mono"}.get(int(info.variant), "scan")
+        dom = {3: "scan_region+scan_tile+tail_deep", 2: "scan_tile+tail_deep", 1: "scan_head+scan_tail", 0: "scan_mono"}.get(int(info.variant), "scan")
         alg_bytes = B * args.rows * args.cols + 16 * ndet  # every frame read once + 16 B per emitted detection
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms else None
         # HBM traffic: PMC counters cannot be read live; the committed profile of the same workload (separate rocprofv3
         # --pmc passes, profiles/r01_traffic.json) gives bytes per frame, scaled here to this batch
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and (args.rows, args.cols, args.kind, args.angle) == (1080, 1920, "faces", 0.0) and int(info.variant) == 2:
+        tname = {3: "r02_traffic.json", 2: "r01_traffic.json"}.get(int(info.variant))
+        tpath = os.path.join(ROOT, "profiles", tname) if tname else None
+        if tpath and os.path.exists(tpath) and (args.rows, args.cols, args.kind, args.angle) == (1080, 1920, "faces", 0.0):
             with open(tpath) as fh:
                 traffic = int(json.load(fh)["hbm_bytes_per_frame"]) * B
         out = {
@@ -553,9 +554,11 @@ def main():
                 "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                 "traffic": traffic,
-                "traffic_note": "profiled offline (profiles/r01_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE per frame x frames); dominated by the deep tail's footprint copies" if traffic else None,
+                "traffic_note": f"profiled offline (profiles/{tname}: 2 x FETCH_SIZE + WRITE_SIZE per frame of the scan kernels, separate rocprofv3 --pmc passes) x frames" if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "compulsory bytes only (each frame read once); the kernel is gather/issue bound, see DESIGN.md",
+                "note": "compulsory bytes only (each frame read once + 16 B per detection); the scan is bound by the LDS pipe (byte gathers, "
+                        "~48 % of its cycles bank conflicts), not by HBM -- DESIGN.md section 4",
+                "achieved_over_timed_step": round(alg_bytes / (elapsed / args.steps) / 1e9, 2),
             },
         }
         out["config3_shard"] = shard_leg

@@ -1549,6 +1549,10 @@ extern "C" pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, 
             }
         }
         if (!sl) {
+            // building a slot (plan tables, allocations, an optional stream capture) is rare and not worth running concurrently:
+            // one at a time, process-wide; the steady state -- calls on existing slots -- stays concurrent
+            static std::mutex build_mu;
+            std::lock_guard<std::mutex> build_lock(build_mu);
             std::unique_ptr<pigo_cascade::RunSlot> ns(new (std::nothrow) pigo_cascade::RunSlot);
             if (!ns) return fail(PIGO_ERR_NOMEM, "out of memory");
             ns->key = key;

@@ -28,8 +28,8 @@ def main():
     scan = lambda d: sum(v["kib_per_step"] for k, v in d.items() if k.startswith("k_scan") or k.startswith("k_tail"))  # noqa: E731
     fk, wk = scan(f), scan(w)
     rec = {
-        "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --frames %d --steps 5 --warmup 2`, "
-                  "scripts/gpu_round1_final.sh; scan kernels only (k_scan_tile*, k_tail_deep*)" % frames,
+        "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --frames %d --steps 5 --warmup 2`; "
+                  "scan kernels only (k_scan_region, k_scan_tile*, k_tail_deep*)" % frames,
         "frames_per_step": frames, "steps_in_profiled_run": steps,
         "fetch_kib_per_step": round(fk, 1), "write_kib_per_step": round(wk, 1),
         "correction": "FETCH_SIZE doubled (gfx950 rocprofv3 note; upper bound for 4 B/lane copies), WRITE_SIZE as reported",
