@@ -201,6 +201,7 @@ struct pigo_plan {
     std::vector<hipEvent_t> events;
     std::vector<const char *> ev_names;
     int n_timed = 0;
+    bool gosort_attr = false;
     int last_nframes = 0;
     int32_t last_flags[3] = {0, 0, 0};   // what the most recent pigo_plan_status read: queue overflow, panic, det_cap overflow
     std::mutex mu;
@@ -470,7 +471,10 @@ bool build_tile_stages(pigo_plan &p)
     for (int i = 0; i < nt; ++i) lo = std::min(lo, c.thr[i]);
     ScanArgs &a = p.args;
     a.nh_lds = std::min(nt, std::max(1, env_int("PIGO_NH_LDS", 28)));
-    a.nh_glb = std::min(nt, std::max(1, (p.rot && !p.rot_lds) ? env_int("PIGO_NH_ROT", 18) : env_int("PIGO_NH_GLB", 28)));
+    // (plans that run variant 3 leave only the big scales -- 1 % of the windows, a quarter of the deep entries -- to the tile
+    // kernel: walking them to the next real threshold, tree 47, before the hand-off costs little there and thins the tail)
+    const bool v3_plan = !p.rot && p.key.dim % 4 == 0 && p.max_frames >= 8;
+    a.nh_glb = std::min(nt, std::max(1, (p.rot && !p.rot_lds) ? env_int("PIGO_NH_ROT", 18) : env_int("PIGO_NH_GLB", v3_plan ? 48 : 28)));
     a.deep_lo = std::min(a.nh_lds, a.nh_glb);
     // LDS table capacity per class: enough for the trees the class walks before handing off; the dense stages'
     // table windows are planned for the smaller of the two so that they fit either
@@ -1450,7 +1454,14 @@ extern "C" pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, c
     k_sort_by_q<<<grid, kThreads, 0, s>>>(d_dets, d_counts, p->det_cap, d_sorted, d_ties);
     // frames with tied Q values: redo the sort with Go's own (unstable) algorithm so that the tie order -- and with it the
     // seed order and the float32 sum order of ClusterDetections -- is the reference's
-    k_gosort_ties<<<nframes, 64, 0, s>>>(d_dets, d_counts, p->det_cap, d_ties, d_sorted);
+    {
+        const int lds_keys = std::min(p->det_cap, kGoSortKeys);
+        if (!p->gosort_attr) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_gosort_ties, hipFuncAttributeMaxDynamicSharedMemorySize, kGoSortKeys * 8));
+            p->gosort_attr = true;
+        }
+        k_gosort_ties<<<nframes, 64, (size_t)lds_keys * 8, s>>>(d_dets, d_counts, p->det_cap, d_ties, d_sorted, lds_keys);
+    }
     if (p->det_cap <= 256 * 64)
         k_cluster<256><<<nframes, 256, 0, s>>>(d_sorted, d_counts, p->det_cap, iou_threshold, d_clusters, d_ccounts, p->d_mq.p);
     else
