@@ -48,6 +48,8 @@ pigo_status fail(pigo_status st, const char *fmt, ...)
         if (e_ != hipSuccess) return fail(PIGO_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+int env_int(const char *name, int dflt);
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -96,6 +98,7 @@ struct pigo_cascade {
     std::vector<float> thr;              // treeThreshold [ntrees]
     DevBuf<int8_t> d_codes;
     DevBuf<float> d_leaf, d_thr;
+    DevBuf<int16_t> d_pass_end;          // k_tail_deep: the lane=tree pass that starts at tree t covers trees [t, d_pass_end[t])
     std::mutex mu;                       // guards the slot list below and pigo_cluster_detections' scratch
     // RunCascade slots: everything one call needs (plan, device + pinned host buffers, a stream, the captured graph of
     // "upload, scan, download").  A call takes a free slot with its parameters (or makes one), so goroutines calling RunCascade on
@@ -170,6 +173,7 @@ struct pigo_plan {
     };
     std::vector<RegionGroup> regions;
     bool region_ok = false;
+    bool tile_patch = true;              // variant 3: do the tile classes' survivors include scales <= kPatchMaxS?
     bool sparse_mode = true;             // variant 3: rungs beyond the region groups by k_scan_sparse (else k_scan_tile + k_tail_deep)
     DevBuf<uint32_t> d_tabr;
     // variant 3, rungs beyond the region groups: k_scan_sparse, one wave per 64 consecutive windows {rung, first window}
@@ -324,6 +328,22 @@ extern "C" pigo_status pigo_cascade_create(const uint8_t *packet, size_t len, in
         HIP_TRY(hipMemcpy(c->d_codes.p, c->codes.data(), c->codes.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_leaf.p, c->pred.data(), c->pred.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_thr.p, c->thr.data(), c->thr.size() * 4, hipMemcpyHostToDevice));
+        // A window can only die at a tree whose threshold is above the cascade's floor value (facefinder: 24 of 468 trees,
+        // 20..40 apart in the deep part), so a lane=tree pass that ends right after the next such tree evaluates no tree a dying
+        // window would not have reached -- a 64-tree pass reads up to 44 trees' pixels (random 64-byte lines of a large
+        // window: the deep tail is bound by exactly that fabric traffic) for nothing.  At least 16 trees per pass.
+        const int nt = (int)ntrees;
+        float lo = c->thr[0];
+        for (int i = 0; i < nt; ++i) lo = std::min(lo, c->thr[i]);
+        std::vector<int16_t> pe((size_t)nt);
+        const bool narrow = env_int("PIGO_DEEP_PASS", 1) != 0;
+        for (int t = 0; t < nt; ++t) {
+            int e = std::min(t + 15, nt - 1);
+            while (e < nt - 1 && !(c->thr[e] > lo)) ++e;
+            pe[(size_t)t] = (int16_t)(narrow ? std::min(e + 1, t + 64) : std::min(nt, t + 64));
+        }
+        HIP_TRY(c->d_pass_end.alloc(pe.size()));
+        HIP_TRY(hipMemcpy(c->d_pass_end.p, pe.data(), pe.size() * 2, hipMemcpyHostToDevice));
     }
     *out = c.release();
     return PIGO_OK;
@@ -667,15 +687,27 @@ bool build_region_groups(pigo_plan &p)
     const int pool_cap = kRegWavePool;
     // leaves + raw codes of the nh trees, per wave a queue of kRegWaveChunk 6-byte and a pool of kRegWavePool 8-byte entries;
     // plus, per group, the offset tables of the chunk-stage trees of every scale of the group
-    const int chunkg[2] = {std::min(kRegWaveChunk, std::max(64, env_int("PIGO_REG_CHUNK0", 512) & ~63)),
-                           std::min(kRegWaveChunk, std::max(64, env_int("PIGO_REG_CHUNK1", 128) & ~63))};
-    const int deepg[2] = {std::max(64, env_int("PIGO_REG_DEEP0", 1536)), std::max(64, env_int("PIGO_REG_DEEP1", 512))};
+    constexpr int NG = 3;  // scale groups: small, mid, big (the big group only when PIGO_REG_S2 names its largest scale)
+    const int chunkg[NG] = {std::min(kRegWaveChunk, std::max(64, env_int("PIGO_REG_CHUNK0", 512) & ~63)),
+                            std::min(kRegWaveChunk, std::max(64, env_int("PIGO_REG_CHUNK1", 128) & ~63)),
+                            std::min(kRegWaveChunk, std::max(64, env_int("PIGO_REG_CHUNK2", 64) & ~63))};
+    const int deepg[NG] = {std::max(64, env_int("PIGO_REG_DEEP0", 1536)), std::max(64, env_int("PIGO_REG_DEEP1", 512)), std::max(64, env_int("PIGO_REG_DEEP2", 256))};
     const size_t max_dyn = (size_t)(160 << 10) - 3072;  // static LDS of k_scan_region: per-scale geometry, counters, thresholds
-    const int smax[2] = {env_int("PIGO_REG_S0", 62), env_int("PIGO_REG_S1", 135)};
-    const int cwmax[2] = {env_int("PIGO_REG_CW0", 320), env_int("PIGO_REG_CW1", 256)};
+    const int smax[NG] = {env_int("PIGO_REG_S0", 62), env_int("PIGO_REG_S1", 135), env_int("PIGO_REG_S2", 0)};
+    const int cwmax[NG] = {env_int("PIGO_REG_CW0", 320), env_int("PIGO_REG_CW1", 256), env_int("PIGO_REG_CW2", 128)};
     int k = 0;
     const int nscales = (int)p.scales.size();
-    for (int g = 0; g < 2 && k < nscales; ++g) {
+    // (a group that does not fit is fatal for the first two -- the plan then runs variant 2 -- and simply dropped for the third:
+    // its rungs stay with the tile classes)
+#define REG_BAIL          \
+    {                     \
+        if (g < 2) return false; \
+        k = k_lo;         \
+        dropped = true;   \
+        break;            \
+    }
+    bool dropped = false;
+    for (int g = 0; g < NG && k < nscales && !dropped; ++g) {
         const int k_lo = k;
         int up = 0, dn = 0;
         while (k < nscales && p.scales[k].s <= smax[g]) {
@@ -684,10 +716,10 @@ bool build_region_groups(pigo_plan &p)
             ++k;
         }
         if (k == k_lo) continue;
-        if (k - k_lo > kRegMaxScales) return false;
+        if (k - k_lo > kRegMaxScales) REG_BAIL;
         const size_t fixed = (size_t)nh * 64 * 8 + (size_t)(kRegThreads / 64) * ((size_t)chunkg[g] * 6 + kRegWavePool * 8) + (size_t)deepg[g] * 8 +
                              (size_t)(k - k_lo) * t_pool * 256;
-        if (fixed + 16384 > max_dyn) return false;
+        if (fixed + 16384 > max_dyn) REG_BAIL;
         const size_t budget = max_dyn - fixed;
         const int halo = up + dn;
         // the largest cell whose region fits; then as many equal cells as the image needs; more, smaller cells when the
@@ -710,13 +742,14 @@ bool build_region_groups(pigo_plan &p)
             if ((long long)r.ncx * r.ncy * p.max_frames >= env_int("PIGO_REG_MIN_REGIONS", 256) || (cw_max <= 32 && ch_max <= 16) || shrink < 0.05) break;
             shrink *= 0.8;
         }
-        if ((size_t)r.pitch * r.rows > budget) return false;
-        if ((long long)std::max(up, dn) * r.pitch + std::max(up, dn) > 32767) return false;  // packed int16 offsets
-        if ((size_t)r.pitch * r.rows + fixed + 2048 >= (1u << 18)) return false;  // pool entries hold an 18-bit LDS address
+        if ((size_t)r.pitch * r.rows > budget) REG_BAIL;
+        if ((long long)std::max(up, dn) * r.pitch + std::max(up, dn) > 32767) REG_BAIL;  // packed int16 offsets
+        if ((size_t)r.pitch * r.rows + fixed + 2048 >= (1u << 18)) REG_BAIL;  // pool entries hold an 18-bit LDS address
         for (int j = k_lo; j < k; ++j) {  // queue entries hold a window's index within (rung, cell) in 16 bits
             const long long ni = (r.cell_h + p.scales[j].step - 1) / p.scales[j].step + 1, nj = (r.cell_w + p.scales[j].step - 1) / p.scales[j].step + 1;
-            if (ni * nj > 65535) return false;
+            if (ni * nj > 65535) REG_BAIL;
         }
+        if (dropped) break;
         r.k_lo = k_lo;
         r.k_hi = k;
         r.halo_up = up;
@@ -727,9 +760,11 @@ bool build_region_groups(pigo_plan &p)
         r.wave_chunk = chunkg[g];
         r.deep_cap = deepg[g];
         for (int j = k_lo; j < k; ++j)
-            if (p.scales[j].s >= (1 << 14)) return false;
+            if (p.scales[j].s >= (1 << 14)) REG_BAIL;
+        if (dropped) break;
         p.regions.push_back({r, fixed + (size_t)r.pitch * r.rows});
     }
+#undef REG_BAIL
     if (p.regions.empty()) return false;
     const int kbig = p.regions.back().args.k_hi;
     p.sparse_groups.clear();
@@ -742,6 +777,8 @@ bool build_region_groups(pigo_plan &p)
         for (uint32_t t = 0; t < cls.ntiles; ++t)
             if ((int)p.tiles2[cls.tile0 + t].x < kbig) ++cls.v3_skip;  // tiles are stored in rung order within a class
     }
+    // the tile classes keep rungs [kbig, ..): their survivors need k_tail_deep's LDS patch only if one of them is small enough
+    p.tile_patch = kbig < nscales && p.scales[kbig].s <= kPatchMaxS;
     return true;
 }
 
@@ -891,9 +928,10 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
                 HIP_TRY(hipMemcpy(p->d_sparse.p, p->sparse_groups.data(), p->sparse_groups.size() * sizeof(uint2), hipMemcpyHostToDevice));
             }
         }
-        HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
     }
     st = plan_alloc_batch(*p, max_frames, det_cap);
     if (st != PIGO_OK) return st;
@@ -906,6 +944,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.tabp = p->d_tabp.p;
     a.tabr = p->d_tabr.p;
     a.codes = c->d_codes.p;
+    a.pass_end = c->d_pass_end.p;
     a.late_waves = std::max(1, std::min(kLateWaves, env_int("PIGO_LATE_WAVES", kLateWaves)));
     a.qb_div = 2;  // per class, see build_tile_classes
 #ifdef PIGO_DEBUG_BUILD
@@ -970,7 +1009,7 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
             ScanArgs ra = a;
             ra.qcap = xcd_cap;
             ra.reg = g.args;
-            mark(first ? "scan_region_small" : "scan_region_mid");
+            mark(first ? "scan_region_small" : &g == &p.regions[1] ? "scan_region_mid" : "scan_region_big");
             if constexpr (!ROT)
                 k_scan_region<<<(uint32_t)a.nframes * (uint32_t)(g.args.ncx * g.args.ncy), kRegThreads, g.dyn_lds, gs>>>(ra);
             if (par && !first) {
@@ -1055,9 +1094,20 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
 
 // variant 2, second half: the two k_tail_deep launches over the queues `a.queue` / `a.qcount` (8 per-XCD queues of xcd_cap
 // entries) with `queue2` (cap2 entries, counter a.qcount[8]) in between
+// `patch` = false: every entry of the queues comes from a scale above kPatchMaxS (see k_tail_deep)
 template <bool ROT, bool GUARD, class Mark>
-void launch_tail(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry *queue2, uint32_t cap2, hipStream_t s, Mark &mark)
+void launch_tail(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry *queue2, uint32_t cap2, hipStream_t s, Mark &mark, bool patch = !ROT)
 {
+    static_assert(!(GUARD && !ROT), "only rotated scans are guarded");
+    const size_t patch_lds = (size_t)kDeepWaves * kPatchBytes;
+    const bool nop = ROT || !patch;
+    const size_t lds1 = p.deep_lds - (nop ? patch_lds : 0), lds2 = p.deep_lds2 - (nop ? patch_lds : 0);
+    // workgroups per CU the grid is sized for.  The patch variant's 130 VGPRs leave room for one resident workgroup (12 waves)
+    // and a grid of two per CU has measured best since round 1; rotated scans (65 VGPRs) gain from two resident ones, the
+    // upright no-patch launches (windows above scale 135 only: few, large footprints) lose with two (58.0 vs 56.4 Gwindows/s).
+    const int cu_max = nop ? env_int("PIGO_TAIL_PER_CU", ROT ? 2 : 1) : 2;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(cu_max, (size_t)(158 << 10) / std::max<size_t>(lds1, 1)));
+    const int per_cu2 = (int)std::max<size_t>(1, std::min<size_t>(nop ? cu_max : 1, (size_t)(158 << 10) / std::max<size_t>(lds2, 1)));
     if (a.deep_lo >= a.ntrees) return;
     mark("tail_deep");
     ScanArgs ta = a;
@@ -1067,7 +1117,12 @@ void launch_tail(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry
     ta.queue2 = queue2;
     ta.qcount2 = a.qcount + 8;
     ta.qcap2 = cap2;
-    k_tail_deep<ROT, GUARD><<<(p.deep_lds * 2 <= (size_t)(158 << 10)) ? 512 : 256, kDeepThreads, p.deep_lds, s>>>(ta);
+    if constexpr (ROT) {
+        k_tail_deep<true, GUARD, false><<<256 * per_cu, kDeepThreads, lds1, s>>>(ta);
+    } else {
+        if (patch) k_tail_deep<false, false, true><<<256 * per_cu, kDeepThreads, lds1, s>>>(ta);
+        else k_tail_deep<false, false, false><<<256 * per_cu, kDeepThreads, lds1, s>>>(ta);
+    }
     if (p.deep_mid < a.ntrees) {
         mark("tail_deep2");
         ScanArgs tb = a;
@@ -1080,7 +1135,12 @@ void launch_tail(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry
         tb.queue2 = nullptr;
         tb.qcount2 = nullptr;
         tb.qcap2 = 0;
-        k_tail_deep<ROT, GUARD><<<256, kDeepThreads, p.deep_lds2, s>>>(tb);
+        if constexpr (ROT) {
+            k_tail_deep<true, GUARD, false><<<256 * per_cu2, kDeepThreads, lds2, s>>>(tb);
+        } else {
+            if (patch) k_tail_deep<false, false, true><<<256, kDeepThreads, lds2, s>>>(tb);
+            else k_tail_deep<false, false, false><<<256 * per_cu2, kDeepThreads, lds2, s>>>(tb);
+        }
     }
 }
 
@@ -1094,25 +1154,30 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
         const int want_chunks = p.pipe_chunks > 0 ? p.pipe_chunks : std::max(2, std::min(8, (a.nframes + 31) / 32));
         // (variant 3 with the sparse kernel finishes every window inside its own launches: nothing to overlap, one chunk)
         const int chunks = (p.tail_stream && !p.profiling && a.nframes >= 16 && a.deep_lo < a.ntrees && !v3) ? want_chunks : 1;
-        if (v3 && !p.sparse_mode && p.side && !p.profiling && a.deep_lo < a.ntrees) {
+        if (v3 && !p.sparse_mode && a.deep_lo < a.ntrees) {
             // Variant 3: the region launches (LDS-bound, they keep every window of their scales to themselves) on `s`, the tile
             // classes of the big scales and their deep tail (vector-memory / latency bound) next to them on the side stream.
             // Two queue sets: A for the tile classes, B for the (rare) spill of the regions' deep lists.
             const long long half = qtotal / 2, half2 = p.qcap2 / 2;
             const uint32_t xcd_cap = (uint32_t)std::min<long long>(half / 8, 0xffffffffLL);
-            (void)hipEventRecord(p.ev_fork, s);
-            (void)hipStreamWaitEvent(p.side, p.ev_fork, 0);
+            // (per-kernel timing runs the same launches one after the other on `s`)
+            const bool fork = p.side && !p.profiling;
+            hipStream_t sa = fork ? p.side : s;
+            if (fork) {
+                (void)hipEventRecord(p.ev_fork, s);
+                (void)hipStreamWaitEvent(p.side, p.ev_fork, 0);
+            }
             ScanArgs aa = a, ab = a;
             aa.queue = p.d_queue.p;
             aa.qcount = p.d_qcount.p;
             ab.queue = p.d_queue.p + half;
             ab.qcount = p.d_qcount.p + 16;
-            launch_tiles<ROT, GUARD>(p, aa, xcd_cap, p.side, mark, true, 2);
-            launch_tail<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, p.side, mark);
-            (void)hipEventRecord(p.ev_join, p.side);
+            launch_tiles<ROT, GUARD>(p, aa, xcd_cap, sa, mark, true, 2);
+            launch_tail<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, sa, mark, p.tile_patch);
+            if (fork) (void)hipEventRecord(p.ev_join, p.side);
             launch_tiles<ROT, GUARD>(p, ab, xcd_cap, s, mark, true, 1);
             launch_tail<ROT, GUARD>(p, ab, xcd_cap, p.d_queue2.p + half2, (uint32_t)half2, s, mark);
-            (void)hipStreamWaitEvent(s, p.ev_join, 0);
+            if (fork) (void)hipStreamWaitEvent(s, p.ev_join, 0);
         } else if (chunks <= 1) {
             const uint32_t xcd_cap = (uint32_t)std::min<long long>(qtotal / 8, 0xffffffffLL);
             launch_tiles<ROT, GUARD>(p, a, xcd_cap, s, mark, v3);
