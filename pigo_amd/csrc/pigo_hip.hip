@@ -1522,10 +1522,10 @@ extern "C" pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, c
     {
         const int lds_keys = std::min(p->det_cap, kGoSortKeys);
         if (!p->gosort_attr) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_gosort_ties, hipFuncAttributeMaxDynamicSharedMemorySize, kGoSortKeys * 8));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_gosort_ties, hipFuncAttributeMaxDynamicSharedMemorySize, kGoSortKeys * 10));
             p->gosort_attr = true;
         }
-        k_gosort_ties<<<nframes, 64, (size_t)lds_keys * 8, s>>>(d_dets, d_counts, p->det_cap, d_ties, d_sorted, lds_keys);
+        k_gosort_ties<<<nframes, 64, (size_t)lds_keys * 10, s>>>(d_dets, d_counts, p->det_cap, d_ties, d_sorted, lds_keys);
     }
     if (p->det_cap <= 256 * 64)
         k_cluster<256><<<nframes, 256, 0, s>>>(d_sorted, d_counts, p->det_cap, iou_threshold, d_clusters, d_ccounts, p->d_mq.p);
