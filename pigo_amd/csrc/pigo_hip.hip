@@ -996,11 +996,20 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
 {
     // variant 3: the region kernel scans the rungs of its scale groups, k_scan_tile only what lies beyond them
     // (what & 1: the region / sparse launches, what & 2: the tile classes)
+#ifdef PIGO_DEBUG_BUILD
+    if (v3 && env_int("PIGO_REG_ONLY", -1) >= 0) what &= 1;
+#endif
     if (v3 && (what & 1)) {
         // a small batch cannot fill the chip with one group's regions: the groups then run next to each other
         const bool par = p.grp_stream && !p.profiling && a.nframes < 8 && p.regions.size() > 1;
         for (const pigo_plan::RegionGroup &g : p.regions) {
             const bool first = &g == &p.regions.front();
+#ifdef PIGO_DEBUG_BUILD
+            {  // per-group phase timers: PIGO_REG_ONLY=g launches that group alone (and no tile class) -- results are incomplete
+                static const int only = env_int("PIGO_REG_ONLY", -1);
+                if (only >= 0 && &g != &p.regions[(size_t)std::min<int>(only, (int)p.regions.size() - 1)]) continue;
+            }
+#endif
             hipStream_t gs = (par && !first) ? p.grp_stream : s;
             if (par && !first) {
                 (void)hipEventRecord(p.ev_gfork, s);
