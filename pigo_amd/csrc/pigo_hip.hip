@@ -335,12 +335,14 @@ extern "C" pigo_status pigo_cascade_create(const uint8_t *packet, size_t len, in
         const int nt = (int)ntrees;
         float lo = c->thr[0];
         for (int i = 0; i < nt; ++i) lo = std::min(lo, c->thr[i]);
-        std::vector<int16_t> pe((size_t)nt);
-        const bool narrow = env_int("PIGO_DEEP_PASS", 1) != 0;
+        // Second table: plain 64-tree passes, for plans of a few frames -- there the tail is a handful of entries per wave and
+        // the call's latency is the number of dependent passes, not the traffic (one 1080p frame: 0.203 ms vs 0.223 ms).
+        std::vector<int16_t> pe((size_t)nt * 2);
         for (int t = 0; t < nt; ++t) {
             int e = std::min(t + 15, nt - 1);
             while (e < nt - 1 && !(c->thr[e] > lo)) ++e;
-            pe[(size_t)t] = (int16_t)(narrow ? std::min(e + 1, t + 64) : std::min(nt, t + 64));
+            pe[(size_t)t] = (int16_t)std::min(e + 1, t + 64);
+            pe[(size_t)nt + t] = (int16_t)std::min(nt, t + 64);
         }
         HIP_TRY(c->d_pass_end.alloc(pe.size()));
         HIP_TRY(hipMemcpy(c->d_pass_end.p, pe.data(), pe.size() * 2, hipMemcpyHostToDevice));
@@ -779,6 +781,7 @@ bool build_region_groups(pigo_plan &p)
     }
     // the tile classes keep rungs [kbig, ..): their survivors need k_tail_deep's LDS patch only if one of them is small enough
     p.tile_patch = kbig < nscales && p.scales[kbig].s <= kPatchMaxS;
+
     return true;
 }
 
@@ -944,7 +947,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.tabp = p->d_tabp.p;
     a.tabr = p->d_tabr.p;
     a.codes = c->d_codes.p;
-    a.pass_end = c->d_pass_end.p;
+    a.pass_end = c->d_pass_end.p + (env_int("PIGO_DEEP_PASS", p->max_frames >= 8 ? 1 : 0) != 0 ? 0 : (size_t)c->ntrees);
     a.late_waves = std::max(1, std::min(kLateWaves, env_int("PIGO_LATE_WAVES", kLateWaves)));
     a.qb_div = 2;  // per class, see build_tile_classes
 #ifdef PIGO_DEBUG_BUILD

@@ -9,6 +9,7 @@ timeout 300 python bench.py --force-dist --frames 32 --steps 3 --warmup 1 --no-c
 timeout 300 python bench.py --kind noise --no-cpu-baseline --no-gray --shard-frames 0 > $O/bench_noise.json 2> $O/bench_noise.err; echo "noise rc=$?"; cut -c1-200 $O/bench_noise.json
 timeout 300 python bench.py --angle 0.8 --no-cpu-baseline --no-gray --shard-frames 0 > $O/bench_rot.json 2> $O/bench_rot.err; echo "rot rc=$?"; cut -c1-200 $O/bench_rot.json
 timeout 300 python bench.py --rows 2160 --cols 3840 --min-size 20 --max-size 2000 --shift 0.05 --scale 1.05 --frames 8 --det-cap 32768 --gather-cap 64 --steps 5 --warmup 2 --no-cpu-baseline --no-gray --shard-frames 0 --verify-frames 1 > $O/bench_4k.json 2> $O/bench_4k.err; echo "4k rc=$?"; cut -c1-200 $O/bench_4k.json; tail -2 $O/bench_4k.err
+timeout 300 python bench.py --frames 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gray --shard-frames 0 --verify-frames 1 --no-single-frame > $O/bench_1frame.json 2> $O/bench_1frame.err; echo "1frame rc=$?"; cut -c1-600 $O/bench_1frame.json
 python scripts/single_frame_latency.py 2>&1 | grep "single 1080p" | tee $O/single_frame.txt
 B="env PIGO_SIDE_STREAM=0 python bench.py --frames 64 --steps 5 --warmup 2 --no-cpu-baseline --no-single-frame --shard-frames 0 --verify-frames 0"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- $B > $O/trace.log 2>&1; echo "trace rc=$?"
@@ -20,3 +21,4 @@ python scripts/summarize_prof.py "round 2 final (scripts/gpu_round2_final.sh): $
 python scripts/make_traffic.py $O/pmc_fetch/p_results.db $O/pmc_write/p_results.db 12 64 > $O/traffic.json 2>$O/traffic.err; echo "traffic rc=$?"; grep hbm_bytes $O/traffic.json
 rm -rf $O/trace $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_sq2
 du -sh $O
+bash scripts/gpu_r2_regdbg.sh > $O/region_phases.txt 2>&1; tail -4 $O/region_phases.txt
