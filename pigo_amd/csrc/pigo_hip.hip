@@ -761,6 +761,9 @@ bool build_region_groups(pigo_plan &p)
         r.nh = nh;
         r.wave_chunk = chunkg[g];
         r.deep_cap = deepg[g];
+        // the 64 x 65 dwords of the first deep pass's codes must fit the wave queues + pools (16.25 KiB)
+        r.deep_lds_codes = (env_int("PIGO_REG_DEEP_LDS", 1) != 0 &&
+                            (size_t)(kRegThreads / 64) * ((size_t)chunkg[g] * 6 + kRegWavePool * 8) >= (size_t)64 * 65 * 4) ? 1 : 0;
         for (int j = k_lo; j < k; ++j)
             if (p.scales[j].s >= (1 << 14)) REG_BAIL;
         if (dropped) break;
