@@ -1120,7 +1120,7 @@ void launch_tail(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry
     const size_t lds1 = p.deep_lds - (nop ? patch_lds : 0), lds2 = p.deep_lds2 - (nop ? patch_lds : 0);
     // workgroups per CU the grid is sized for.  The patch variant's 130 VGPRs leave room for one resident workgroup (12 waves)
     // and a grid of two per CU has measured best since round 1; rotated scans (65 VGPRs) gain from two resident ones, the
-    // upright no-patch launches (windows above scale 135 only: few, large footprints) lose with two (58.0 vs 56.4 Gwindows/s).
+    // upright no-patch launches (windows of the scales above the region groups only: few, large footprints) lose with two (58.0 vs 56.4 Gwindows/s).
     const int cu_max = nop ? env_int("PIGO_TAIL_PER_CU", ROT ? 2 : 1) : 2;
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(cu_max, (size_t)(158 << 10) / std::max<size_t>(lds1, 1)));
     const int per_cu2 = (int)std::max<size_t>(1, std::min<size_t>(nop ? cu_max : 1, (size_t)(158 << 10) / std::max<size_t>(lds2, 1)));
