@@ -14,7 +14,9 @@
 #define PIGO_HPP
 
 #include <cstdint>
+#include <array>
 #include <memory>
+#include <utility>
 #include <stdexcept>
 #include <string>
 #include <functional>
@@ -245,6 +247,109 @@ inline PuplocCascade NewPuplocCascade(int device = 0) { return PuplocCascade(dev
 
 // NewPigo, core/pigo.go:46
 inline Pigo NewPigo(int device = 0) { return Pigo(device); }
+
+// ---- batch / multi-GPU extension (no reference counterpart; pigo_hip.h "batch" and "multi-GPU" sections) ----------------
+// Thin owners over the C handles for hosts that keep frames in device memory.  Pointers named d_* are device pointers the
+// caller allocated with HIP; `stream` is a hipStream_t (nullptr = default stream).
+
+// One RCCL communicator per process/GPU: rank 0 calls Comm::UniqueId() and ships the bytes to the other ranks.
+class Comm {
+  public:
+    using Id = std::array<uint8_t, PIGO_COMM_ID_BYTES>;
+    static Id UniqueId()
+    {
+        Id id{};
+        detail::check(pigo_comm_unique_id(id.data()), "pigo_comm_unique_id");
+        return id;
+    }
+    // world == 1 needs no id (and no RCCL)
+    Comm(const Id *id, int rank, int world, int device)
+    {
+        pigo_comm *c = nullptr;
+        detail::check(pigo_comm_init(id ? id->data() : nullptr, rank, world, device, &c), "pigo_comm_init");
+        h_.reset(c, [](pigo_comm *p) { pigo_comm_destroy(p); });
+    }
+    int Rank() const
+    {
+        int r = 0, w = 0;
+        detail::check(pigo_comm_info(h_.get(), &r, &w), "pigo_comm_info");
+        return r;
+    }
+    int World() const
+    {
+        int r = 0, w = 0;
+        detail::check(pigo_comm_info(h_.get(), &r, &w), "pigo_comm_info");
+        return w;
+    }
+    pigo_comm *handle() const { return h_.get(); }
+
+  private:
+    std::shared_ptr<pigo_comm> h_;
+};
+
+// contiguous shard [lo, hi) of `nframes` frames for `rank`
+inline std::pair<int, int> ShardBounds(int nframes, int rank, int world)
+{
+    int lo = 0, hi = 0;
+    pigo_shard_bounds(nframes, rank, world, &lo, &hi);
+    return {lo, hi};
+}
+
+// one row of the all-gathered wire format -> the frame's (possibly truncated) list and its true length
+inline std::vector<Detection> UnpackList(const int32_t *wire_row, int gather_cap, int *true_count = nullptr)
+{
+    std::vector<pigo_det> raw((size_t)(gather_cap > 0 ? gather_cap : 1));
+    int n = 0, tc = 0;
+    detail::check(pigo_unpack_list(wire_row, gather_cap, raw.data(), (int)raw.size(), &n, &tc), "pigo_unpack_list");
+    if (true_count) *true_count = tc;
+    std::vector<Detection> out((size_t)n);
+    for (int i = 0; i < n; ++i) out[(size_t)i] = Detection{raw[(size_t)i].row, raw[(size_t)i].col, raw[(size_t)i].scale, raw[(size_t)i].q};
+    return out;
+}
+
+// A scan plan: fixed CascadeParams geometry + angle, workspace for max_frames device-resident frames.
+class Plan {
+  public:
+    Plan(const Pigo &pg, int rows, int cols, int dim, int minSize, int maxSize, double shiftFactor, double scaleFactor, double angle,
+         int maxFrames, int detCap)
+    {
+        pigo_plan *p = nullptr;
+        detail::check(pigo_plan_create(pg.handle(), rows, cols, dim, minSize, maxSize, shiftFactor, scaleFactor, angle, maxFrames, detCap, &p),
+                      "pigo_plan_create");
+        h_.reset(p, [](pigo_plan *q) { pigo_plan_destroy(q); });
+    }
+    // RunCascade on every frame (asynchronous; call Status() after synchronising the stream)
+    void Run(const uint8_t *d_frames, size_t frame_stride, int nframes, pigo_det *d_dets, int32_t *d_counts, void *stream = nullptr) const
+    {
+        detail::check(pigo_plan_run(h_.get(), d_frames, frame_stride, nframes, d_dets, d_counts, stream), "pigo_plan_run");
+    }
+    // ClusterDetections on every frame's list
+    void Cluster(const pigo_det *d_dets, const int32_t *d_counts, int nframes, double iouThreshold, pigo_det *d_sorted, pigo_det *d_clusters,
+                 int32_t *d_ccounts, int32_t *d_ties = nullptr, void *stream = nullptr) const
+    {
+        detail::check(pigo_plan_cluster(h_.get(), d_dets, d_counts, nframes, iouThreshold, d_sorted, d_clusters, d_ccounts, d_ties, stream),
+                      "pigo_plan_cluster");
+    }
+    // this rank's shard: scan + cluster + one all-gather of the wire rows of all ranks into d_gathered
+    void RunBatchSharded(const Comm &comm, const uint8_t *d_frames, size_t frame_stride, int nframes_local, int frames_per_rank,
+                         double iouThreshold, int gather_cap, int32_t *d_gathered, void *stream = nullptr) const
+    {
+        detail::check(pigo_run_batch_sharded(h_.get(), comm.handle(), d_frames, frame_stride, nframes_local, frames_per_rank, iouThreshold,
+                                             gather_cap, d_gathered, stream),
+                      "pigo_run_batch_sharded");
+    }
+    void Status() const { detail::check(pigo_plan_status(h_.get()), "pigo_plan_status"); }
+    pigo_plan_info_t Info() const
+    {
+        pigo_plan_info_t info{};
+        detail::check(pigo_plan_info(h_.get(), &info), "pigo_plan_info");
+        return info;
+    }
+    pigo_plan *handle() const { return h_.get(); }
+
+  private:
+    std::shared_ptr<pigo_plan> h_;
+};
 
 }  // namespace pigo
 #endif  // PIGO_HPP

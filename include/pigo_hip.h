@@ -172,7 +172,7 @@ typedef struct {
     int32_t n_ladder;          /* all rungs, including the ones larger than the image */
     int32_t tiles_per_frame;   /* workgroups per frame of the head kernel */
     int32_t n_head_trees;      /* trees evaluated by the dense head kernel */
-    int32_t variant;           /* 0 = monolithic scan, 1 = head + survivor-queue tail, 2 = whole cascade per LDS tile */
+    int32_t variant;           /* 0 = monolithic scan, 1 = head + survivor-queue tail, 2 = whole cascade per LDS tile, 3 = region kernel */
     int32_t max_frames, det_cap;
     int64_t queue_capacity;    /* survivor-queue entries shared by the batch */
     int64_t workspace_bytes;
@@ -184,7 +184,11 @@ pigo_status pigo_plan_info(const pigo_plan *p, pigo_plan_info_t *info);
  *   1 = the first design (dense head kernel + survivor queue + tail kernel, pixels gathered from global memory); it is
  *       compiled into the debug build only (python -m pigo_amd.build --debug) -- PIGO_ERR_PARAM in the release library,
  *   2 = one workgroup takes a tile of windows through the whole cascade out of an LDS copy of the tile's
- *       pixels (default when the cascade has depth 6). */
+ *       pixels (default when the cascade has depth 6),
+ *   3 = one workgroup per CU owns an LDS-resident region of a frame for a whole group of scales (k_scan_region); the
+ *       scales above the groups go through variant 2's kernels.  Default for upright plans with dim % 4 == 0 and
+ *       max_frames >= 8; PIGO_ERR_PARAM for plans it cannot serve (rotated scans, other strides).
+ * All variants produce identical results. */
 pigo_status pigo_plan_set_variant(pigo_plan *p, int variant);
 
 /* Asynchronous scan of `nframes` (<= max_frames) device-resident frames.  `d_frames` points to

@@ -41,8 +41,33 @@ int main(int argc, char **argv)
             eye_ok = eye.Row > d.Row - d.Scale / 2 && eye.Row < d.Row && eye.Col > d.Col - d.Scale / 2 && eye.Col < d.Col;
             std::printf(" eye=(%d,%d,%.3f) eye_ok=%d", eye.Row, eye.Col, eye.Scale, eye_ok ? 1 : 0);
         }
+        // batch / multi-GPU extension: a plan for the same parameters, a world-size-1 communicator (no RCCL needed), the shard
+        // arithmetic and the wire codec (host side of what pigo_run_batch_sharded packs on the device)
+        bool wire_ok = true;
+        {
+            const pigo::Plan plan(pg, 400, 320, 320, 20, 1000, 0.2, 1.1, 0.0, 8, 256);
+            wire_ok = wire_ok && plan.Info().max_frames == 8 && plan.Info().windows_per_frame > 0;
+            const pigo::Comm comm(nullptr, 0, 1, 0);
+            wire_ok = wire_ok && comm.Rank() == 0 && comm.World() == 1;
+            const auto b0 = pigo::ShardBounds(10, 0, 4), b3 = pigo::ShardBounds(10, 3, 4);
+            wire_ok = wire_ok && b0.first == 0 && b0.second == 3 && b3.first == 8 && b3.second == 10;
+            const int gcap = 4;
+            std::vector<pigo_det> lists(2 * 8);
+            const int32_t counts[2] = {2, 6};  // the second list is longer than gather_cap: truncated row, true count kept
+            for (int i = 0; i < 16; ++i) lists[(size_t)i] = pigo_det{i, 2 * i, 3 * i, 0.5f * (float)i};
+            std::vector<int32_t> wire(3 * pigo_wire_words(gcap));
+            pigo::detail::check(pigo_pack_lists(lists.data(), counts, 2, 3, 8, gcap, wire.data()), "pigo_pack_lists");
+            int tc = -1;
+            const auto l0 = pigo::UnpackList(wire.data(), gcap, &tc);
+            wire_ok = wire_ok && l0.size() == 2 && tc == 2 && l0[1].Row == 1 && l0[1].Col == 2 && l0[1].Q == 0.5f;
+            const auto l1 = pigo::UnpackList(wire.data() + pigo_wire_words(gcap), gcap, &tc);
+            wire_ok = wire_ok && l1.size() == 4 && tc == 6 && l1[3].Row == 11;
+            const auto l2 = pigo::UnpackList(wire.data() + 2 * pigo_wire_words(gcap), gcap, &tc);
+            wire_ok = wire_ok && l2.empty() && tc == 0;  // padding row
+        }
+        std::printf(" wire_ok=%d", wire_ok ? 1 : 0);
         std::printf("\n");
-        return cl.empty() || !gray_ok || !eye_ok ? 1 : 0;
+        return cl.empty() || !gray_ok || !eye_ok || !wire_ok ? 1 : 0;
     } catch (const pigo::Panic &e) {
         std::printf("panic: %s\n", e.what());
         return 3;

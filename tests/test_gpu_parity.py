@@ -391,7 +391,7 @@ def test_cpp_mirror_runs_on_gpu(tmp_path):
                            "-o", exe, "-L" + csrc, "-lpigo_hip", "-Wl,-rpath," + csrc])
     r = subprocess.run([exe, os.path.join(root, "pigo_amd", "data", "facefinder"), os.path.join(root, "pigo_amd", "data", "sample_gray_320x400.bin"),
                         os.path.join(root, "pigo_amd", "data", "puploc")], capture_output=True, text=True)
-    assert r.returncode == 0 and "dets=4 clusters=1 (206,154,261," in r.stdout and "gray177=1" in r.stdout and "eye_ok=1" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    assert r.returncode == 0 and "dets=4 clusters=1 (206,154,261," in r.stdout and "gray177=1" in r.stdout and "eye_ok=1" in r.stdout and "wire_ok=1" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
 # ---- the path bench.py times: many 1080p frames, chunked pipeline, side stream, per-XCD queues -----------------------------
