@@ -693,7 +693,9 @@ bool build_region_groups(pigo_plan &p)
     const int chunkg[NG] = {std::min(kRegWaveChunk, std::max(64, env_int("PIGO_REG_CHUNK0", 512) & ~63)),
                             std::min(kRegWaveChunk, std::max(64, env_int("PIGO_REG_CHUNK1", 128) & ~63)),
                             std::min(kRegWaveChunk, std::max(64, env_int("PIGO_REG_CHUNK2", 64) & ~63))};
-    const int deepg[NG] = {std::max(64, env_int("PIGO_REG_DEEP0", 1536)), std::max(64, env_int("PIGO_REG_DEEP1", 512)), std::max(64, env_int("PIGO_REG_DEEP2", 256))};
+    // (deep lists of 1024 / 512 entries: 768 / 1024 / 1536 for the small group measure 65.3 / 65.5 / 64.7 k -- the LDS goes to
+    // the cell instead --, 256 for the mid group starts to spill on the benchmark frames)
+    const int deepg[NG] = {std::max(64, env_int("PIGO_REG_DEEP0", 1024)), std::max(64, env_int("PIGO_REG_DEEP1", 512)), std::max(64, env_int("PIGO_REG_DEEP2", 256))};
     const size_t max_dyn = (size_t)(160 << 10) - 3072;  // static LDS of k_scan_region: per-scale geometry, counters, thresholds
     // (group limits: 51 / 148 measured best after the deep list got cheaper -- 42…51 / 148 within 0.3 %, 62 / 135 3 % slower)
     const int smax[NG] = {env_int("PIGO_REG_S0", 51), env_int("PIGO_REG_S1", 148), env_int("PIGO_REG_S2", 0)};

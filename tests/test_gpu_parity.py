@@ -439,6 +439,41 @@ def test_benchmarked_path_1080p_batch_against_oracle(pg, orc, chunks, angle, mon
     assert sum(len(w) for w in want) > (1000 if angle == 0.0 else 10)
 
 
+def test_region_deep_list_spill_goes_through_the_tail(pg, orc, monkeypatch):
+    """k_scan_region collects the windows alive after tree 27 in a per-region LDS list; a full list spills into
+    k_tail_deep's survivor queue.  With the lists cut to 64 entries every face region of these frames spills: the result must
+    not change (raw lists bit-exact against the oracle).  core/pigo.go:113-147, :212-258."""
+    import threading
+    import torch
+    from pigo_amd import batch
+    monkeypatch.setenv("PIGO_REG_DEEP0", "64")
+    monkeypatch.setenv("PIGO_REG_DEEP1", "64")
+    n, rows, cols = 8, 1080, 1920
+    frames = synth.make_frames("faces", n, rows, cols, seed=4321)
+    d_frames = torch.from_numpy(frames).cuda()
+    want = [None] * n
+
+    def work(f):
+        want[f] = orc.run_cascade(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1, 0.0)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(n)]
+    for t in th:
+        t.start()
+    plan = batch.ScanPlan(pg, rows, cols, MinSize=20, MaxSize=1000, ShiftFactor=0.1, ScaleFactor=1.1, angle=0.0, max_frames=n, det_cap=1024)
+    assert plan.info().variant == 3
+    dets, counts = plan.alloc_outputs(n)
+    for rep in range(2):
+        plan.run(d_frames, dets, counts)
+    torch.cuda.synchronize()
+    plan.status()
+    for t in th:
+        t.join()
+    got = batch.dets_to_numpy(dets, counts)
+    for f in range(n):
+        assert_same_dets(got[f], want[f], f"deep-list spill frame {f}", Q_TOL_RAW)
+    assert sum(len(w) for w in want) > 200
+
+
 def test_sharded_entry_point_world1_matches_plain_path(pg, orc):
     """pigo_run_batch_sharded (the C ABI a Go / C++ host shards with) at world size 1: scan + cluster + device-side
     packing must give exactly the wire rows of the plain path's lists, padding rows included; raw-list mode as well."""
