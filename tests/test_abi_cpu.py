@@ -120,6 +120,23 @@ def test_cpp_mirror_compiles_and_links(tmp_path):
         assert r.returncode == 0 and "clusters=1 (206,154,261," in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
+def test_pruned_go_sort_equals_plain_go_sort_on_the_host(tmp_path):
+    """k_gosort_ties does not sort the parts of a list that hold no equal Q values (gosort::KeyData::prune).  The same
+    host/device code, compiled for the host only, must give exactly what the plain restatement of Go's pdqsort gives on 600
+    random lists with ties of every density (tests/gosort_prune_check.hip).  core/pigo.go:264-266."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "gosort_prune_check")
+    subprocess.check_call([hipcc, "--cuda-host-only", "-O1", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "gosort_prune_check.hip"), "-o", exe],
+                          stderr=subprocess.DEVNULL)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok lists=600"), (r.returncode, r.stdout, r.stderr)
+    assert int(r.stdout.split("kept_from_stable=")[1]) > 10000  # the pruning did happen
+
+
 def test_one_hip_runtime_per_process_whatever_the_import_order():
     """libpigo_hip.so and PyTorch must share ONE libamdhip64 / libhsa-runtime64: with two HSA runtimes in a process the
     second one finds no GPUs (seen on the GPU box when pigo_amd was loaded before torch)."""
