@@ -556,8 +556,9 @@ def main():
                 "traffic": traffic,
                 "traffic_note": f"profiled offline (profiles/{tname}: 2 x FETCH_SIZE + WRITE_SIZE per frame of the scan kernels, separate rocprofv3 --pmc passes) x frames" if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "compulsory bytes only (each frame read once + 16 B per detection); the scan is bound by the LDS pipe (byte gathers, "
-                        "~48 % of its cycles bank conflicts), not by HBM -- DESIGN.md section 4",
+                "note": "compulsory bytes only (each frame read once + 16 B per detection); the scan is not bound by HBM: the region kernel by its "
+                        "waves' dependent VALU->LDS chains (LDS pipe ~54 % busy, ~44 % of that bank conflicts), the 1 % largest windows by the "
+                        "texture-address rate of 64-line byte gathers -- DESIGN.md section 4",
                 "achieved_over_timed_step": round(alg_bytes / (elapsed / args.steps) / 1e9, 2),
             },
         }
