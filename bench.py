@@ -265,7 +265,7 @@ def main():
         gather_mode = args.gather
         if gather_mode == "cabi":
             try:
-                comm = distributed.Comm.from_torch(local_rank)
+                comm = distributed.Comm.from_torch(local_rank, force_rccl=True)  # world 1 too: a real one-rank RCCL communicator
             except Exception as e:  # noqa: BLE001 -- reported, not swallowed
                 print(f"[rank {rank}] pigo_comm_init failed ({e}); using torch.distributed for the all-gather", file=sys.stderr)
                 comm = None
@@ -273,6 +273,8 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 comm, gather_mode = None, "torch (pigo_comm_init failed)"
+            else:  # which collective the C ABI will issue: ncclAllGather, or (world 1 without an id) a device copy
+                gather_mode = "cabi/rccl" if comm.uses_rccl else "cabi/memcpy"
         gathered = torch.zeros((world * B, 1 + 4 * gcap), dtype=torch.int32, device=dev)
 
     def step():

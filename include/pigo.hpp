@@ -262,7 +262,7 @@ class Comm {
         detail::check(pigo_comm_unique_id(id.data()), "pigo_comm_unique_id");
         return id;
     }
-    // world == 1 needs no id (and no RCCL)
+    // world == 1 needs no id (and no RCCL); world == 1 WITH an id builds a real one-rank RCCL communicator
     Comm(const Id *id, int rank, int world, int device)
     {
         pigo_comm *c = nullptr;
@@ -281,6 +281,7 @@ class Comm {
         detail::check(pigo_comm_info(h_.get(), &r, &w), "pigo_comm_info");
         return w;
     }
+    bool UsesRccl() const { return pigo_comm_uses_rccl(h_.get()) != 0; }
     pigo_comm *handle() const { return h_.get(); }
 
   private:

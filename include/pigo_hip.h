@@ -254,12 +254,18 @@ pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n);
  *                pigo_shard_bounds(nframes, rank, world, &lo, &hi)
  *                pigo_run_batch_sharded(plan, comm, d_frames + lo*stride, stride, hi - lo, frames_per_rank, iou, gather_cap,
  *                                       d_gathered, stream)
- * world == 1 needs no RCCL at all (id may be NULL). */
+ * world == 1 needs no RCCL at all: with id == NULL the "gather" is one device-to-device copy.  world == 1 WITH an id (from
+ * pigo_comm_unique_id) builds a real one-rank RCCL communicator and pigo_run_batch_sharded goes through ncclAllGather exactly
+ * as on a multi-GPU node -- the way to exercise the collective on a single-GPU box (pigo_comm_uses_rccl tells which).
+ * Errors: a rank whose scan fails inside pigo_run_batch_sharded still contributes zero-count padding rows to the collective
+ * before it returns the error, so its peers do not hang; a failure of pigo_comm_init or of the collective itself is fatal for
+ * the communicator on every rank (destroy it and start over). */
 typedef struct pigo_comm pigo_comm;
 #define PIGO_COMM_ID_BYTES 128
 pigo_status pigo_comm_unique_id(uint8_t id[PIGO_COMM_ID_BYTES]);
 pigo_status pigo_comm_init(const uint8_t id[PIGO_COMM_ID_BYTES], int rank, int world, int device, pigo_comm **out);
 pigo_status pigo_comm_info(const pigo_comm *c, int *rank, int *world);
+int pigo_comm_uses_rccl(const pigo_comm *c); /* 1: the all-gather is ncclAllGather; 0: world == 1 without an id, a plain copy */
 void pigo_comm_destroy(pigo_comm *c);
 /* contiguous shard [lo, hi) of `nframes` frames for `rank`; earlier ranks take the remainder */
 void pigo_shard_bounds(int nframes, int rank, int world, int *lo, int *hi);

@@ -1646,7 +1646,8 @@ extern "C" pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, 
             // building a slot (plan tables, allocations, an optional stream capture) is rare and not worth running concurrently:
             // one at a time, process-wide; the steady state -- calls on existing slots -- stays concurrent
             static std::mutex build_mu;
-            std::lock_guard<std::mutex> build_lock(build_mu);
+            std::unique_lock<std::mutex> build_lock(build_mu, std::defer_lock);
+            if (!env_int("PIGO_NO_BUILD_MU", 0)) build_lock.lock();  // (diagnostic switch: reproduce the round-2 abort)
             std::unique_ptr<pigo_cascade::RunSlot> ns(new (std::nothrow) pigo_cascade::RunSlot);
             if (!ns) return fail(PIGO_ERR_NOMEM, "out of memory");
             ns->key = key;
@@ -2103,8 +2104,11 @@ extern "C" pigo_status pigo_comm_init(const uint8_t id[PIGO_COMM_ID_BYTES], int 
     c->rank = rank;
     c->world = world;
     c->device = device;
-    if (world > 1) {
-        if (!id) return fail(PIGO_ERR_PARAM, "id is NULL");
+    // world > 1 needs the id; world == 1 WITH an id builds a real one-rank RCCL communicator too (the caller asked for one by
+    // calling pigo_comm_unique_id): the collective of pigo_run_batch_sharded then runs through ncclAllGather exactly as on a
+    // multi-GPU node, which is how a single-GPU box tests that path.  world == 1 without an id needs no RCCL at all.
+    if (world > 1 && !id) return fail(PIGO_ERR_PARAM, "id is NULL");
+    if (id) {
         const Rccl *r = nullptr;
         pigo_status st = rccl_load(&r);
         if (st != PIGO_OK) return st;
@@ -2124,6 +2128,8 @@ extern "C" pigo_status pigo_comm_info(const pigo_comm *c, int *rank, int *world)
     if (world) *world = c->world;
     return PIGO_OK;
 }
+
+extern "C" int pigo_comm_uses_rccl(const pigo_comm *c) { return c && c->comm ? 1 : 0; }
 
 extern "C" void pigo_comm_destroy(pigo_comm *c)
 {
@@ -2208,27 +2214,38 @@ extern "C" pigo_status pigo_run_batch_sharded(pigo_plan *p, pigo_comm *comm, con
     int32_t *d_counts = p->sh_counts.p, *d_ccounts = p->sh_counts.p + p->max_frames;
     const pigo_det *lists = p->sh_dets.p;
     const int32_t *lcounts = d_counts;
+    const size_t row_words = (size_t)frames_per_rank * words;
+    // From here on a failure must not leave the peers alone in the collective (they have enqueued their ncclAllGather and
+    // would wait for this rank forever): the rank still contributes its rows -- all zero-count padding -- and then reports
+    // the error.  A non-OK return of the collective itself is fatal for the communicator (destroy it).
+    pigo_status st = PIGO_OK;
     if (nframes_local > 0) {
-        pigo_status st = pigo_plan_run(p, d_frames, frame_stride, nframes_local, p->sh_dets.p, d_counts, stream);
-        if (st != PIGO_OK) return st;
-        if (clustered) {
+        st = pigo_plan_run(p, d_frames, frame_stride, nframes_local, p->sh_dets.p, d_counts, stream);
+        if (st == PIGO_OK && clustered) {
             st = pigo_plan_cluster(p, p->sh_dets.p, d_counts, nframes_local, iou_threshold, p->sh_sorted.p, p->sh_clusters.p, d_ccounts, nullptr,
                                    stream);
-            if (st != PIGO_OK) return st;
             lists = p->sh_clusters.p;
             lcounts = d_ccounts;
         }
     }
-    k_pack_lists<<<frames_per_rank, 256, 0, s>>>(lists, lcounts, nframes_local, p->det_cap, gather_cap, p->sh_wire.p);
-    HIP_TRY(hipGetLastError());
-    const size_t row_words = (size_t)frames_per_rank * words;
-    if (world > 1) {
+    const std::string first_error = st != PIGO_OK ? g_last_error : std::string();
+    if (st == PIGO_OK) {
+        k_pack_lists<<<frames_per_rank, 256, 0, s>>>(lists, lcounts, nframes_local, p->det_cap, gather_cap, p->sh_wire.p);
+        if (hipGetLastError() != hipSuccess) st = fail(PIGO_ERR_HIP, "k_pack_lists launch failed");
+    }
+    if (st != PIGO_OK) (void)hipMemsetAsync(p->sh_wire.p, 0, row_words * 4, s);  // zero-count padding rows
+    if (comm && comm->comm) {
         const Rccl *r = nullptr;
-        pigo_status st = rccl_load(&r);
-        if (st != PIGO_OK) return st;
+        const pigo_status rs = rccl_load(&r);
+        if (rs != PIGO_OK) return rs;
         RCCL_TRY(r, r->all_gather(p->sh_wire.p, d_gathered, row_words, kNcclInt32, comm->comm, s));
     } else {
+        if (world > 1) return fail(PIGO_ERR_PARAM, "communicator of %d ranks without an RCCL handle", world);
         HIP_TRY(hipMemcpyAsync(d_gathered + (size_t)rank * row_words, p->sh_wire.p, row_words * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if (st != PIGO_OK) {
+        g_last_error = first_error.empty() ? g_last_error : first_error;
+        return st;
     }
     return PIGO_OK;
 }

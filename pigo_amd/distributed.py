@@ -69,11 +69,18 @@ class Comm:
         core.check(core.load_library().pigo_comm_unique_id(buf), "comm_unique_id")
         return bytes(buf)
 
+    @property
+    def uses_rccl(self) -> bool:
+        """True when the all-gather of run_batch_sharded is ncclAllGather (world > 1, or world == 1 built with an id)."""
+        return bool(self.L.pigo_comm_uses_rccl(self._h))
+
     @classmethod
-    def from_torch(cls, device: int, group=None):
+    def from_torch(cls, device: int, group=None, force_rccl: bool = False):
+        """``force_rccl``: at world size 1 build a real one-rank RCCL communicator as well (ncclGetUniqueId ->
+        ncclCommInitRank -> ncclAllGather), so that a single-GPU box runs the very collective an 8-GPU node does."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 and world > 1 else None]
+        box = [cls.unique_id() if rank == 0 and (world > 1 or force_rccl) else None]
         if world > 1:
             dist.broadcast_object_list(box, src=0, group=group)
         return cls(rank, world, device, box[0])

@@ -111,6 +111,7 @@ def test_comm_world1_needs_no_rccl_and_no_gpu():
     r, w = C.c_int(-1), C.c_int(-1)
     core.check(core.load_library().pigo_comm_info(c._h, C.byref(r), C.byref(w)))
     assert (r.value, w.value) == (0, 1)
+    assert c.uses_rccl is False  # (a one-rank communicator built WITH an id goes through RCCL: tests/test_gpu_parity.py)
     with pytest.raises(ValueError):
         distributed.Comm(2, 2, 0, bytes(128))  # rank outside [0, world)
 

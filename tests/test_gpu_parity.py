@@ -474,9 +474,12 @@ def test_region_deep_list_spill_goes_through_the_tail(pg, orc, monkeypatch):
     assert sum(len(w) for w in want) > 200
 
 
-def test_sharded_entry_point_world1_matches_plain_path(pg, orc):
+@pytest.mark.parametrize("rccl", [False, True])
+def test_sharded_entry_point_world1_matches_plain_path(pg, orc, rccl):
     """pigo_run_batch_sharded (the C ABI a Go / C++ host shards with) at world size 1: scan + cluster + device-side
-    packing must give exactly the wire rows of the plain path's lists, padding rows included; raw-list mode as well."""
+    packing must give exactly the wire rows of the plain path's lists, padding rows included; raw-list mode as well.
+    rccl=True builds a REAL one-rank RCCL communicator (ncclGetUniqueId -> ncclCommInitRank) so that the rows travel through
+    ncclAllGather -- the collective an 8-GPU node runs -- instead of the world-1 device copy."""
     import torch
     from pigo_amd import batch, distributed
     n, per, rows, cols, gcap = 11, 16, 270, 480, 8
@@ -487,7 +490,8 @@ def test_sharded_entry_point_world1_matches_plain_path(pg, orc):
     plan.run(d_frames, dets, counts)
     _, clusters, ccounts, _ = plan.cluster(dets, counts, 0.2)
     torch.cuda.synchronize()
-    comm = distributed.Comm(0, 1, 0)
+    comm = distributed.Comm(0, 1, 0, distributed.Comm.unique_id() if rccl else None)
+    assert comm.uses_rccl is rccl
     for iou, lists, lcounts in ((0.2, clusters, ccounts), (-1.0, dets, counts)):
         wire = distributed.run_batch_sharded(plan, comm, d_frames, per, iou, gcap)
         torch.cuda.synchronize()
@@ -501,6 +505,28 @@ def test_sharded_entry_point_world1_matches_plain_path(pg, orc):
     got0, cnt0 = distributed.unpack_list_host(distributed.run_batch_sharded(plan, comm, d_frames, per, 0.2, gcap)[0].cpu().numpy(), gcap)
     assert cnt0 == len(want0)
     assert_same_dets(got0, want0[:gcap], "sharded frame 0", Q_TOL_RAW)
+
+
+def test_sharded_rank_with_a_failing_scan_still_joins_the_collective(pg):
+    """A rank whose scan cannot run (here: more frames than the plan holds is refused up front, so provoke the failure inside
+    the call with a misaligned frame pointer) must still enqueue its -- zero-count -- rows into the all-gather before it
+    reports the error: its peers have already entered ncclAllGather and would hang otherwise (one-rank RCCL communicator)."""
+    import torch
+    from pigo_amd import batch, distributed
+    n, per, rows, cols, gcap = 4, 4, 270, 480, 8
+    d_frames = torch.from_numpy(synth.make_frames("faces", n + 1, rows, cols, seed=5)).cuda()
+    plan = batch.ScanPlan(pg, rows, cols, max_frames=4, det_cap=256)
+    comm = distributed.Comm(0, 1, 0, distributed.Comm.unique_id())
+    out = torch.full((per, 1 + 4 * gcap), 7, dtype=torch.int32, device="cuda")
+    bad = d_frames.view(-1)[1:1 + n * rows * cols].view(n, rows, cols)  # frame pointer not a multiple of 4: pigo_plan_run refuses
+    with pytest.raises(ValueError):
+        distributed.run_batch_sharded(plan, comm, bad, per, 0.2, gcap, out=out)
+    torch.cuda.synchronize()
+    assert int(out.abs().sum()) == 0  # the collective ran, with padding rows
+    wire = distributed.run_batch_sharded(plan, comm, d_frames[:n], per, 0.2, gcap, out=out)  # the communicator is still usable
+    torch.cuda.synchronize()
+    plan.status()
+    assert int(wire[:, 0].sum()) > 0
 
 
 def batch_lists_to_host(lists, n):
