@@ -217,8 +217,11 @@ pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, const int32_
  * the last run are incomplete; pigo_plan_run_sync handles this by re-running with the monolithic
  * kernel) or some frame has more than det_cap detections (its list is truncated, and which records
  * were kept is not deterministic; d_counts holds the true count: re-plan with a larger det_cap).
- * pigo_last_error() says which. */
+ * pigo_last_error() says which, pigo_plan_last_flags() returns the raw words pigo_plan_status read last: queue_overflow
+ * (bit 0 a tile's LDS queue, bit 1 a survivor queue, bit 2 the second-level tail queue: "results incomplete, re-run"),
+ * would_panic, det_cap_overflow ("list truncated, re-plan with a larger det_cap"). */
 pigo_status pigo_plan_status(pigo_plan *p);
+pigo_status pigo_plan_last_flags(const pigo_plan *p, int32_t *queue_overflow, int32_t *would_panic, int32_t *det_cap_overflow);
 
 /* Synchronous convenience wrapper: run + synchronise + overflow fallback. */
 pigo_status pigo_plan_run_sync(pigo_plan *p, const uint8_t *d_frames, size_t frame_stride, int nframes, pigo_det *d_dets,

@@ -85,6 +85,13 @@ class ScanPlan:
         """Call after synchronising: raises PigoPanic / PigoError(capacity) like the single-frame API."""
         core.check(self.L.pigo_plan_status(self._h), "plan_status")
 
+    def last_flags(self):
+        """(queue_overflow, would_panic, det_cap_overflow) as the last ``status()`` read them (pigo_plan_last_flags): tells
+        'results incomplete, re-run' (queue) from 'list truncated, re-plan with a larger det_cap'."""
+        q, pn, dc = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        core.check(self.L.pigo_plan_last_flags(self._h, C.byref(q), C.byref(pn), C.byref(dc)), "plan_last_flags")
+        return q.value, pn.value, dc.value
+
     def alloc_cluster_outputs(self, dets, counts):
         torch = _torch()
         return torch.zeros_like(dets), torch.zeros_like(dets), torch.zeros_like(counts), torch.zeros_like(counts)

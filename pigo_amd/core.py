@@ -48,7 +48,7 @@ class PlanInfo(C.Structure):
 ABI_SYMBOLS = [
     "pigo_last_error", "pigo_device_count", "pigo_cascade_create", "pigo_cascade_info", "pigo_cascade_tables", "pigo_cascade_destroy",
     "pigo_run_cascade", "pigo_cluster_detections", "pigo_sort_by_q", "pigo_plan_create", "pigo_plan_destroy", "pigo_plan_info",
-    "pigo_plan_set_variant", "pigo_plan_run", "pigo_plan_cluster", "pigo_plan_status", "pigo_plan_run_sync", "pigo_plan_set_profiling",
+    "pigo_plan_set_variant", "pigo_plan_run", "pigo_plan_cluster", "pigo_plan_status", "pigo_plan_last_flags", "pigo_plan_run_sync", "pigo_plan_set_profiling",
     "pigo_plan_last_timings", "pigo_plan_last_queue_count", "pigo_plan_debug_stats", "pigo_plan_debug_trace",
     "pigo_rgb_to_grayscale", "pigo_gray_batch",
     "pigo_puploc_create", "pigo_puploc_info", "pigo_puploc_destroy", "pigo_puploc_run_detector", "pigo_get_landmark_point",
@@ -136,6 +136,7 @@ def load_library():
     L.pigo_get_landmark_point.argtypes = [vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, vp, vp, vp]
     L.pigo_puploc_run_batch.argtypes = [vp, vp, sz, i32, i32, i32, i32, dbl, vp, vp, vp, i32, vp, vp]
     L.pigo_puploc_status.argtypes = [vp]
+    L.pigo_plan_last_flags.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.pigo_comm_unique_id.argtypes = [vp]
     L.pigo_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     L.pigo_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]

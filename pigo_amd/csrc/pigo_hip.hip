@@ -109,6 +109,8 @@ struct pigo_cascade {
     DevBuf<uint8_t> d_frame;
     DevBuf<pigo_det> d_dets, d_sorted, d_clusters;
     DevBuf<int32_t> d_small;             // counts etc.
+    DevBuf<int32_t> d_cl_seeds, d_cl_tmpn;   // long lists: k_cluster_seeds / _members / _compact
+    DevBuf<pigo_det> d_cl_tmp;
     DevBuf<float> d_mq;
 };
 
@@ -192,6 +194,10 @@ struct pigo_plan {
     DevBuf<QEntry> d_queue;
     DevBuf<uint32_t> d_qcount;
     DevBuf<int32_t> d_ties;              // per-frame tie counts when the caller does not ask for them
+    // ClusterDetections for long lists (k_cluster_seeds / _members / _compact): seed lists, per-seed clusters before compaction
+    DevBuf<int32_t> d_cl_seeds, d_cl_nseeds, d_cl_tmpn;
+    DevBuf<pigo_det> d_cl_tmp;
+    int cluster_mode = -1;               // -1: by det_cap, 0: k_cluster (one workgroup per frame), 1: the seeds/members kernels
     DevBuf<RawDet> d_raw;
     DevBuf<int32_t> d_flags;
     DevBuf<float> d_mq;
@@ -289,6 +295,7 @@ extern "C" pigo_status pigo_cascade_create(const uint8_t *packet, size_t len, in
     if (len < 16) return fail(PIGO_ERR_PACKET, "Unpack: packet of %zu bytes is shorter than the 16-byte header", len);
     const uint32_t depth = le32(packet + 8), ntrees = le32(packet + 12);
     if (depth > 12) return fail(PIGO_ERR_PARAM, "Unpack: tree depth %u not supported (max 12)", depth);
+    if (ntrees > 32767) return fail(PIGO_ERR_PARAM, "Unpack: %u trees not supported (max 32767: tree indices travel as int16)", ntrees);
     const size_t nodes = (size_t)1 << depth;
     const size_t ncode = 4 * nodes - 4;  // pigo.go:81
     const size_t rec = ncode + 4 * nodes + 4;
@@ -495,7 +502,7 @@ bool build_tile_stages(pigo_plan &p)
     a.nh_lds = std::min(nt, std::max(1, env_int("PIGO_NH_LDS", 28)));
     // (plans that run variant 3 leave only the big scales -- 1 % of the windows, a quarter of the deep entries -- to the tile
     // kernel: walking them to the next real threshold, tree 47, before the hand-off costs little there and thins the tail)
-    const bool v3_plan = !p.rot && p.key.dim % 4 == 0 && p.max_frames >= 8;
+    const bool v3_plan = (!p.rot || p.rot_lds) && p.key.dim % 4 == 0 && p.max_frames >= 8;
     a.nh_glb = std::min(nt, std::max(1, (p.rot && !p.rot_lds) ? env_int("PIGO_NH_ROT", 18) : env_int("PIGO_NH_GLB", v3_plan ? 48 : 28)));
     a.deep_lo = std::min(a.nh_lds, a.nh_glb);
     // LDS table capacity per class: enough for the trees the class walks before handing off; the dense stages'
@@ -677,7 +684,8 @@ bool build_region_groups(pigo_plan &p)
 {
     p.regions.clear();
     const ScanArgs &a = p.args;
-    if (!p.tile_ok || p.rot || p.key.dim % 4 != 0 || p.scales.empty()) return false;
+    // (rotated scans: only where the clamp-free LDS form exists -- rot_lds: no Go panic possible, see k_scan_tile's loader)
+    if (!p.tile_ok || (p.rot && !p.rot_lds) || p.key.dim % 4 != 0 || p.scales.empty()) return false;
     const int nh = std::min(a.nh_lds, a.nh_glb);
     if (nh < 1 || nh > kTabTrees || a.deep_lo != nh) return false;
     // chunk stages: the leading stages that end below the pooling tree
@@ -716,8 +724,10 @@ bool build_region_groups(pigo_plan &p)
         const int k_lo = k;
         int up = 0, dn = 0;
         while (k < nscales && p.scales[k].s <= smax[g]) {
-            up = std::max(up, (p.scales[k].s + 1) / 2);
-            dn = std::max(dn, (127 * p.scales[k].s) >> 8);
+            // footprint of a window above/left and below/right of its centre (build_tile_classes: upright ceil(s/2) and
+            // (127*s) >> 8, rotated the extreme rotated offsets of the rung)
+            up = std::max(up, p.scales[k].up);
+            dn = std::max(dn, p.scales[k].down);
             ++k;
         }
         if (k == k_lo) continue;
@@ -854,33 +864,46 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     build_tile_classes(*p);  // also fills ScaleDesc::pitch / up
 
     HIP_TRY(hipSetDevice(c->device));
+    // Everything a plan uploads or builds on the device goes through ONE private stream and is waited for with
+    // hipStreamSynchronize: no device-wide call and nothing on the legacy null stream.  hipDeviceSynchronize() is refused by
+    // the runtime ("operation not permitted when stream is capturing") while ANY thread of the process captures a stream --
+    // and it invalidates that thread's capture on the way: that was round 2's abort, a RunCascade slot being captured
+    // (PIGO_GRAPH_FRAMES) while another goroutine's call built its plan.
+    struct BuildStream {
+        hipStream_t s = nullptr;
+        ~BuildStream()
+        {
+            if (s) (void)hipStreamDestroy(s);
+        }
+    } bs;
+    HIP_TRY(hipStreamCreateWithFlags(&bs.s, hipStreamNonBlocking));
     const int nscales = (int)p->scales.size();
     HIP_TRY(p->d_scales.alloc(nscales));
     HIP_TRY(p->d_tiles.alloc(p->tiles.size()));
     HIP_TRY(p->d_flags.alloc(4));
-    HIP_TRY(hipMemset(p->d_flags.p, 0, 16));
+    HIP_TRY(hipMemsetAsync(p->d_flags.p, 0, 16, bs.s));
     const size_t tab_n = (size_t)nscales * c->ntrees * c->nodes;
     HIP_TRY(p->d_tab.alloc(tab_n));
     if (nscales) {
-        HIP_TRY(hipMemcpy(p->d_scales.p, p->scales.data(), nscales * sizeof(ScaleDesc), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p->d_tiles.p, p->tiles.data(), p->tiles.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(p->d_scales.p, p->scales.data(), nscales * sizeof(ScaleDesc), hipMemcpyHostToDevice, bs.s));
+        HIP_TRY(hipMemcpyAsync(p->d_tiles.p, p->tiles.data(), p->tiles.size() * 4, hipMemcpyHostToDevice, bs.s));
     }
     if (tab_n) {
         const int blocks = (int)std::min<size_t>((tab_n + 255) / 256, 4096);
-        k_build_tab<<<blocks, 256>>>(c->d_codes.p, p->d_scales.p, p->d_tab.p, nscales, (int)c->ntrees, c->nodes, key.dim, p->rot ? 1 : 0,
-                                     kQCos[p->angle_idx], kQSin[p->angle_idx]);
+        k_build_tab<<<blocks, 256, 0, bs.s>>>(c->d_codes.p, p->d_scales.p, p->d_tab.p, nscales, (int)c->ntrees, c->nodes, key.dim, p->rot ? 1 : 0,
+                                              kQCos[p->angle_idx], kQSin[p->angle_idx]);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipDeviceSynchronize());
     }
+    HIP_TRY(hipStreamSynchronize(bs.s));
     if (p->tile_ok && nscales) {
         HIP_TRY(p->d_tiles2.alloc(p->tiles2.size()));
-        HIP_TRY(hipMemcpy(p->d_tiles2.p, p->tiles2.data(), p->tiles2.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(p->d_tiles2.p, p->tiles2.data(), p->tiles2.size() * sizeof(uint2), hipMemcpyHostToDevice, bs.s));
         HIP_TRY(p->d_tabp.alloc((size_t)nscales * c->ntrees * 64));
         const size_t n = (size_t)nscales * c->ntrees * 64;
-        k_build_tabp<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256>>>(c->d_codes.p, p->d_scales.p, p->d_tabp.p, nscales, (int)c->ntrees, p->rot ? 1 : 0,
-                                                                                   kQCos[p->angle_idx], kQSin[p->angle_idx]);
+        k_build_tabp<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256, 0, bs.s>>>(c->d_codes.p, p->d_scales.p, p->d_tabp.p, nscales, (int)c->ntrees, p->rot ? 1 : 0,
+                                                                                            kQCos[p->angle_idx], kQSin[p->angle_idx]);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipStreamSynchronize(bs.s));
         const int max_dyn = (160 << 10) - 1024;
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
@@ -926,15 +949,18 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
                 for (int j = g.args.k_lo; j < g.args.k_hi; ++j) sreg[j].pitch = g.args.pitch;
             DevBuf<ScaleDesc> d_sreg;
             HIP_TRY(d_sreg.alloc(nscales));
-            HIP_TRY(hipMemcpy(d_sreg.p, sreg.data(), nscales * sizeof(ScaleDesc), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpyAsync(d_sreg.p, sreg.data(), nscales * sizeof(ScaleDesc), hipMemcpyHostToDevice, bs.s));
             HIP_TRY(p->d_tabr.alloc(n));
-            k_build_tabp<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256>>>(c->d_codes.p, d_sreg.p, p->d_tabr.p, nscales, (int)c->ntrees, 0, 0, 0);
+            k_build_tabp<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256, 0, bs.s>>>(c->d_codes.p, d_sreg.p, p->d_tabr.p, nscales, (int)c->ntrees, p->rot ? 1 : 0,
+                                                                                                kQCos[p->angle_idx], kQSin[p->angle_idx]);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipFuncSetAttribute((const void *)k_scan_region, hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 3072));
+            HIP_TRY(hipStreamSynchronize(bs.s));  // (before sreg / d_sreg go out of scope)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_scan_region<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 3072));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_scan_region<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 3072));
             if (!p->sparse_groups.empty()) {
                 HIP_TRY(p->d_sparse.alloc(p->sparse_groups.size()));
-                HIP_TRY(hipMemcpy(p->d_sparse.p, p->sparse_groups.data(), p->sparse_groups.size() * sizeof(uint2), hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpyAsync(p->d_sparse.p, p->sparse_groups.data(), p->sparse_groups.size() * sizeof(uint2), hipMemcpyHostToDevice, bs.s));
+                HIP_TRY(hipStreamSynchronize(bs.s));
             }
         }
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
@@ -960,7 +986,8 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.stats = nullptr;
     if (env_int("PIGO_DEBUG_STATS", 0)) {
         HIP_TRY(p->d_stats.alloc(65536 * 8 + 16 * 256 + 256 * 8));
-        HIP_TRY(hipMemset(p->d_stats.p, 0, (65536 * 8 + 16 * 256 + 256 * 8) * 8));
+        HIP_TRY(hipMemsetAsync(p->d_stats.p, 0, (65536 * 8 + 16 * 256 + 256 * 8) * 8, bs.s));
+        HIP_TRY(hipStreamSynchronize(bs.s));
         a.stats = p->d_stats.p;
     }
 #endif
@@ -995,6 +1022,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     if (p->variant == 1) p->variant = 0;
 #endif
     if (p->variant < 0 || p->variant > 3) p->variant = 0;
+    HIP_TRY(hipStreamSynchronize(bs.s));
     out = std::move(p);
     return PIGO_OK;
 }
@@ -1020,20 +1048,19 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
             }
 #endif
             hipStream_t gs = (par && !first) ? p.grp_stream : s;
-            if (par && !first) {
+            if (par && first) {  // fork BEFORE the first group's launch, so that the others really run next to it
                 (void)hipEventRecord(p.ev_gfork, s);
-                (void)hipStreamWaitEvent(gs, p.ev_gfork, 0);
+                (void)hipStreamWaitEvent(p.grp_stream, p.ev_gfork, 0);
             }
             ScanArgs ra = a;
             ra.qcap = xcd_cap;
             ra.reg = g.args;
             mark(first ? "scan_region_small" : &g == &p.regions[1] ? "scan_region_mid" : "scan_region_big");
-            if constexpr (!ROT)
-                k_scan_region<<<(uint32_t)a.nframes * (uint32_t)(g.args.ncx * g.args.ncy), kRegThreads, g.dyn_lds, gs>>>(ra);
-            if (par && !first) {
-                (void)hipEventRecord(p.ev_gjoin, gs);
-                (void)hipStreamWaitEvent(s, p.ev_gjoin, 0);
-            }
+            k_scan_region<ROT><<<(uint32_t)a.nframes * (uint32_t)(g.args.ncx * g.args.ncy), kRegThreads, g.dyn_lds, gs>>>(ra);
+        }
+        if (par) {  // one join after the last group
+            (void)hipEventRecord(p.ev_gjoin, p.grp_stream);
+            (void)hipStreamWaitEvent(s, p.ev_gjoin, 0);
         }
         if (p.sparse_mode && !p.sparse_groups.empty()) {
             ScanArgs sa = a;
@@ -1430,6 +1457,15 @@ extern "C" pigo_status pigo_plan_status(pigo_plan *p)
     return PIGO_OK;
 }
 
+extern "C" pigo_status pigo_plan_last_flags(const pigo_plan *p, int32_t *queue_overflow, int32_t *would_panic, int32_t *det_cap_overflow)
+{
+    if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
+    if (queue_overflow) *queue_overflow = p->last_flags[0];
+    if (would_panic) *would_panic = p->last_flags[1];
+    if (det_cap_overflow) *det_cap_overflow = p->last_flags[2];
+    return PIGO_OK;
+}
+
 extern "C" pigo_status pigo_plan_run_sync(pigo_plan *p, const uint8_t *d_frames, size_t frame_stride, int nframes, pigo_det *d_dets,
                                           int32_t *d_counts, void *stream)
 {
@@ -1528,9 +1564,22 @@ extern "C" pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, c
     if (nframes < 0 || nframes > p->max_frames) return fail(PIGO_ERR_PARAM, "nframes outside the plan's range");
     if (nframes == 0) return PIGO_OK;
     if (!d_dets || !d_counts || !d_sorted || !d_clusters || !d_ccounts) return fail(PIGO_ERR_PARAM, "NULL device pointer");
-    if (p->det_cap > 65536) return fail(PIGO_ERR_PARAM, "GPU clustering supports det_cap <= 65536");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(p->c->device));
+    // Lists of a few hundred detections (1080p) are served by one workgroup per frame; plans that can hold long lists (the 4K
+    // stress config: thousands of detections, hundreds of clusters per frame) by the seeds / members / compact kernels, which
+    // spread a frame's clusters over the chip and have no length limit.  PIGO_CLUSTER_V2=0/1 forces one.
+    const int mode = p->cluster_mode >= 0 ? p->cluster_mode : env_int("PIGO_CLUSTER_V2", -1);
+    const bool v2 = mode >= 0 ? mode != 0 : p->det_cap > 4096;
+    if (!v2 && p->det_cap > 65536) return fail(PIGO_ERR_PARAM, "k_cluster supports det_cap <= 65536 (PIGO_CLUSTER_V2=0 was forced)");
+    if (v2) {
+        std::lock_guard<std::mutex> lock(p->mu);
+        const size_t need = (size_t)p->max_frames * p->det_cap;
+        if (p->d_cl_seeds.n < need) HIP_TRY(p->d_cl_seeds.alloc(need));
+        if (p->d_cl_tmpn.n < need) HIP_TRY(p->d_cl_tmpn.alloc(need));
+        if (p->d_cl_tmp.n < need) HIP_TRY(p->d_cl_tmp.alloc(need));
+        if (p->d_cl_nseeds.n < (size_t)p->max_frames) HIP_TRY(p->d_cl_nseeds.alloc(p->max_frames));
+    }
     if (!d_ties) d_ties = p->d_ties.p;
     HIP_TRY(hipMemsetAsync(d_ties, 0, (size_t)nframes * 4, s));
     dim3 grid((unsigned)((p->det_cap + kThreads - 1) / kThreads), (unsigned)nframes);
@@ -1545,10 +1594,18 @@ extern "C" pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, c
         }
         k_gosort_ties<<<nframes, 64, (size_t)lds_keys * 10, s>>>(d_dets, d_counts, p->det_cap, d_ties, d_sorted, lds_keys);
     }
-    if (p->det_cap <= 256 * 64)
+    if (v2) {
+        k_cluster_seeds<<<nframes, kSeedThreads, 0, s>>>(d_sorted, d_counts, p->det_cap, iou_threshold, p->d_cl_seeds.p, p->d_cl_nseeds.p);
+        // one wave per cluster; waves stride over a frame's seeds (the grid cannot depend on the count without a host round trip)
+        const unsigned gx = (unsigned)std::max(1, std::min((p->det_cap + 3) / 4, std::max(8, 2048 / nframes)));
+        k_cluster_members<<<dim3(gx, (unsigned)nframes), kMemberThreads, 0, s>>>(d_sorted, d_counts, p->det_cap, iou_threshold, p->d_cl_seeds.p, p->d_cl_nseeds.p,
+                                                                                  p->d_cl_tmp.p, p->d_cl_tmpn.p);
+        k_cluster_compact<<<nframes, 256, 0, s>>>(p->d_cl_nseeds.p, p->det_cap, p->d_cl_tmp.p, p->d_cl_tmpn.p, d_clusters, d_ccounts);
+    } else if (p->det_cap <= 256 * 64) {
         k_cluster<256><<<nframes, 256, 0, s>>>(d_sorted, d_counts, p->det_cap, iou_threshold, d_clusters, d_ccounts, p->d_mq.p);
-    else
+    } else {
         k_cluster<1024><<<nframes, 1024, 0, s>>>(d_sorted, d_counts, p->det_cap, iou_threshold, d_clusters, d_ccounts, p->d_mq.p);
+    }
     HIP_TRY(hipGetLastError());
     return PIGO_OK;
 }
@@ -1567,7 +1624,6 @@ extern "C" pigo_status pigo_cluster_detections(pigo_cascade *c, pigo_det *dets, 
     if (!c) return fail(PIGO_ERR_PARAM, "cascade is NULL");
     if (n_out) *n_out = 0;
     if (n < 0 || (n > 0 && !dets)) return fail(PIGO_ERR_PARAM, "bad detection list");
-    if (n > 65536) return fail(PIGO_ERR_PARAM, "ClusterDetections: more than 65536 detections");
     if (n == 0) return PIGO_OK;  // clusters := []Detection{}  (pigo.go:280)
     pigo_sort_by_q(dets, n);     // pigo.go:264-266, in place like the reference
     std::lock_guard<std::mutex> lock(c->mu);
@@ -1579,10 +1635,22 @@ extern "C" pigo_status pigo_cluster_detections(pigo_cascade *c, pigo_det *dets, 
     const int32_t h_small[2] = {n, 0};
     HIP_TRY(hipMemcpy(c->d_small.p, h_small, 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_sorted.p, dets, (size_t)n * sizeof(pigo_det), hipMemcpyHostToDevice));
-    if (n <= 256 * 64)
+    const int mode = env_int("PIGO_CLUSTER_V2", -1);
+    if (mode >= 0 ? mode != 0 : n > 2048) {  // long list: seeds first, then every cluster on its own wave (no length limit)
+        if (c->d_cl_seeds.n < (size_t)n) HIP_TRY(c->d_cl_seeds.alloc(n));
+        if (c->d_cl_tmpn.n < (size_t)n) HIP_TRY(c->d_cl_tmpn.alloc(n));
+        if (c->d_cl_tmp.n < (size_t)n) HIP_TRY(c->d_cl_tmp.alloc(n));
+        k_cluster_seeds<<<1, kSeedThreads>>>(c->d_sorted.p, c->d_small.p, n, iou_threshold, c->d_cl_seeds.p, c->d_small.p + 2);
+        k_cluster_members<<<dim3((unsigned)std::max(1, std::min((n + 3) / 4, 2048)), 1u), kMemberThreads>>>(c->d_sorted.p, c->d_small.p, n, iou_threshold, c->d_cl_seeds.p,
+                                                                                                              c->d_small.p + 2, c->d_cl_tmp.p, c->d_cl_tmpn.p);
+        k_cluster_compact<<<1, 256>>>(c->d_small.p + 2, n, c->d_cl_tmp.p, c->d_cl_tmpn.p, c->d_clusters.p, c->d_small.p + 1);
+    } else if (n <= 256 * 64) {
         k_cluster<256><<<1, 256>>>(c->d_sorted.p, c->d_small.p, n, iou_threshold, c->d_clusters.p, c->d_small.p + 1, c->d_mq.p);
-    else
+    } else if (n <= 65536) {
         k_cluster<1024><<<1, 1024>>>(c->d_sorted.p, c->d_small.p, n, iou_threshold, c->d_clusters.p, c->d_small.p + 1, c->d_mq.p);
+    } else {
+        return fail(PIGO_ERR_PARAM, "k_cluster supports at most 65536 detections (PIGO_CLUSTER_V2=0 was forced)");
+    }
     HIP_TRY(hipGetLastError());
     int32_t ncl = 0;
     HIP_TRY(hipMemcpy(&ncl, c->d_small.p + 1, 4, hipMemcpyDeviceToHost));
@@ -1643,11 +1711,7 @@ extern "C" pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, 
             }
         }
         if (!sl) {
-            // building a slot (plan tables, allocations, an optional stream capture) is rare and not worth running concurrently:
-            // one at a time, process-wide; the steady state -- calls on existing slots -- stays concurrent
-            static std::mutex build_mu;
-            std::unique_lock<std::mutex> build_lock(build_mu, std::defer_lock);
-            if (!env_int("PIGO_NO_BUILD_MU", 0)) build_lock.lock();  // (diagnostic switch: reproduce the round-2 abort)
+            // (slots are built concurrently: plan_build stays on its own stream, see there)
             std::unique_ptr<pigo_cascade::RunSlot> ns(new (std::nothrow) pigo_cascade::RunSlot);
             if (!ns) return fail(PIGO_ERR_NOMEM, "out of memory");
             ns->key = key;

@@ -165,6 +165,38 @@ def test_cluster_semantics_and_ties(pg, orc):
     assert_same_dets(got, want, "clusters of 3000", Q_TOL_RAW)
 
 
+@pytest.mark.parametrize("v2", ["0", "1"])
+def test_cluster_kernels_agree_on_sweep_lists(pg, orc, v2, monkeypatch):
+    """Both ClusterDetections implementations -- k_cluster (one workgroup per frame) and the seeds / members / compact kernels
+    for long lists -- against the oracle on the same lists: random boxes at every threshold the reference's callers use
+     plus 1.0 and a negative one, scale-0 windows (IoU with itself is NaN: a seed without a cluster),
+    lists that straddle the 256-candidate block of k_cluster_seeds.  core/pigo.go:262-308."""
+    monkeypatch.setenv("PIGO_CLUSTER_V2", v2)
+    rng = np.random.default_rng(77)
+    for n in (1, 2, 13, 64, 255, 256, 257, 700, 1500):
+        rows = [(int(rng.integers(20, 400)), int(rng.integers(20, 600)), int(rng.choice([0, 20, 24, 40, 60, 90, 140])),
+                 float(rng.integers(1, 4000)) / 16.0) for _ in range(n)]
+        for iou in (0.0, 0.01, 0.15, 0.2, 0.6, 1.0, -0.5):
+            a, b = core.make_dets(rows), oracle.make_dets(rows)
+            got, want = pg.ClusterDetections(a, iou), orc.cluster_detections(b, iou)
+            assert_same_dets(a, b, f"sorted n={n}", Q_TOL_RAW)
+            assert_same_dets(got, want, f"clusters n={n} iou={iou} v2={v2}", Q_TOL_RAW)
+
+
+def test_cluster_detections_has_no_length_limit(pg, orc):
+    """The reference's ClusterDetections takes a slice of any length (core/pigo.go:262); round 2 refused more than 65,536
+    detections.  70,000 boxes spread over a large canvas (so that the O(seeds x n) sweep stays small), ties included."""
+    rng = np.random.default_rng(5)
+    n = 70000
+    rows = [(int(r), int(c), int(s), float(q) / 8.0) for r, c, s, q in
+            zip(rng.integers(100, 60000, n), rng.integers(100, 60000, n), rng.choice([400, 640, 900, 1500], n), rng.integers(1, 2000, n))]
+    a, b = core.make_dets(rows), oracle.make_dets(rows)
+    got, want = pg.ClusterDetections(a, 0.2), orc.cluster_detections(b, 0.2)
+    assert_same_dets(a, b, "sorted 70000", Q_TOL_RAW)
+    assert len(want) > 100
+    assert_same_dets(got, want, "clusters of 70000", Q_TOL_RAW)
+
+
 # ---- full-size configs (BASELINE.json configs 2, 4, 5) ------------------------------------------------------------
 
 
@@ -331,7 +363,9 @@ def test_batch_detection_overflow_is_reported_not_silent(pg):
     with pytest.raises(core.PigoError, match="det_cap"):
         plan.status()
     assert int(counts.max()) > 16
+    assert plan.last_flags() == (0, 0, 1)  # not a queue overflow: the caller re-plans with a larger det_cap instead of re-running
     plan.status()  # the flag is cleared by the report
+    assert plan.last_flags() == (0, 0, 0)
     big = batch.ScanPlan(pg, 1080, 1920, max_frames=3, det_cap=int(counts.max()))
     d2, c2 = big.alloc_outputs(3)
     big.run(d_frames, d2, c2)
@@ -420,6 +454,7 @@ def test_benchmarked_path_1080p_batch_against_oracle(pg, orc, chunks, angle, mon
     for t in th:
         t.start()
     plan = batch.ScanPlan(pg, rows, cols, MinSize=20, MaxSize=1000, ShiftFactor=0.1, ScaleFactor=1.1, angle=angle, max_frames=n, det_cap=1024)
+    assert int(plan.info().variant) == 3  # the region kernel: upright AND rotated (landscape frames: clamp-free LDS form)
     dets, counts = plan.alloc_outputs(n)
     cl_out = plan.alloc_cluster_outputs(dets, counts)
     for rep in range(2):  # the second run reuses every queue, counter and event of the first
@@ -567,6 +602,58 @@ def test_run_cascade_is_reentrant_four_threads_one_handle(orc, graph, monkeypatc
     # two threads, SAME parameters: two slots of one key
     errors.clear()
     th = [threading.Thread(target=work, args=(0,)) for _ in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+
+
+def test_slot_capture_next_to_plan_builds_on_other_handles(orc, monkeypatch):
+    """Round 2's abort, root cause pinned with rocgdb (gpurun_out/r3/abort_gdb_*.txt): while one thread captures the
+    upload-scan-download graph of a new RunCascade slot (hipStreamBeginCapture, thread-local mode), another thread's
+    plan_build called hipDeviceSynchronize() -- refused "when stream is capturing" even from a foreign thread, and the capture
+    is invalidated on the way.  plan_build now stays on a private stream (no device-wide call, nothing on the null stream), so
+    slot builds, plan builds and hipMalloc-heavy calls on OTHER handles may run next to a capture without a process lock."""
+    import threading
+    import torch
+    from pigo_amd import batch
+    monkeypatch.setenv("PIGO_GRAPH_FRAMES", "1")
+    packet = synth.facefinder_bytes()
+    imgs = [synth.syn_faces(120 + 8 * k, 160 + 4 * k, seed=70 + k) for k in range(6)]
+    wants = [orc.run_cascade(im, im.shape[0], im.shape[1], im.shape[1], 20, 1000, 0.1, 1.1, 0.0) for im in imgs]
+    errors, stop = [], threading.Event()
+
+    def capture_slots():  # every call has new parameters: a new slot, a new plan, a new captured graph
+        try:
+            pg = core.NewPigo(0).Unpack(packet)
+            for rep in range(3):
+                for k, im in enumerate(imgs):
+                    got = pg.RunCascade(_cp(im, im.shape[0], im.shape[1], im.shape[1], 20 + rep, 1000, 0.1, 1.1), 0.0)
+                    if rep == 0:
+                        assert_same_dets(got, wants[k], f"capture thread frame {k}", Q_TOL_RAW)
+        except Exception as e:  # noqa: BLE001
+            errors.append(("capture", repr(e)))
+        finally:
+            stop.set()
+
+    def build_plans(seed):  # a different handle: plan builds (tables, uploads, ~20 allocations each) and batch runs
+        try:
+            pg = core.NewPigo(0).Unpack(packet)
+            k = 0
+            while not stop.is_set() or k < 4:
+                rows, cols = 96 + 8 * ((k + seed) % 5), 128 + 4 * ((k + seed) % 7)
+                plan = batch.ScanPlan(pg, rows, cols, max_frames=8, det_cap=256)
+                fr = torch.from_numpy(synth.make_frames("faces", 8, rows, cols, seed=seed + k)).cuda()
+                dets, counts = plan.alloc_outputs(8)
+                plan.run(fr, dets, counts, sync=True)
+                k += 1
+                if k > 200:
+                    break
+        except Exception as e:  # noqa: BLE001
+            errors.append(("build", repr(e)))
+
+    th = [threading.Thread(target=capture_slots)] + [threading.Thread(target=build_plans, args=(s,)) for s in (1, 2)]
     for t in th:
         t.start()
     for t in th:
