@@ -178,6 +178,12 @@ struct pigo_plan {
     bool tile_patch = true;              // variant 3: do the tile classes' survivors include scales <= kPatchMaxS?
     bool sparse_mode = true;             // variant 3: rungs beyond the region groups by k_scan_sparse (else k_scan_tile + k_tail_deep)
     DevBuf<uint32_t> d_tabr;
+    // variant 3, rungs beyond the region groups: survivors binned by position for k_tail_patch
+    bool patch_ok = false;
+    PatchArgs patch{};
+    size_t patch_lds = 0;
+    DevBuf<uint4> d_patch_ent;
+    DevBuf<uint32_t> d_patch_bcount, d_patch_active;
     // variant 3, rungs beyond the region groups: k_scan_sparse, one wave per 64 consecutive windows {rung, first window}
     std::vector<uint2> sparse_groups;
     DevBuf<uint2> d_sparse;
@@ -818,7 +824,7 @@ pigo_status plan_alloc_batch(pigo_plan &p, int max_frames, int det_cap)
     qcap = (qcap + kTailChunk - 1) / kTailChunk * kTailChunk;
     p.qcap = qcap;
     HIP_TRY(p.d_queue.alloc((size_t)qcap * max_frames));
-    HIP_TRY(p.d_qcount.alloc(std::max(max_frames, 32)));  // [0..7] per-XCD queues, [8] second-level queue; [16..24] the second set
+    HIP_TRY(p.d_qcount.alloc(std::max(max_frames, 64)));  // [0..7] per-XCD queues, [8] second-level queue; [16..24] the second set; [32..39] bucket lists
     p.qcap2 = std::max<long long>(4096, (qcap * (long long)max_frames) / 8);
     HIP_TRY(p.d_queue2.alloc((size_t)p.qcap2));
     HIP_TRY(p.d_raw.alloc((size_t)det_cap * max_frames));
@@ -970,6 +976,32 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     }
     st = plan_alloc_batch(*p, max_frames, det_cap);
     if (st != PIGO_OK) return st;
+    // Variant 3, upright: the survivors of the rungs beyond the region groups are binned by position for k_tail_patch
+    // (PIGO_PATCH=0: round 2's late mode + k_tail_deep instead).
+    if (p->region_ok && !p->rot && env_int("PIGO_PATCH", 1) != 0 && nscales <= 2047 && (int)c->ntrees >= kPatchHead) {
+        PatchArgs &P = p->patch;
+        P.cell_log2 = std::max(4, std::min(8, env_int("PIGO_PATCH_CELL_LOG2", 6)));
+        P.ncx = ((key.cols - 1) >> P.cell_log2) + 1;
+        P.nb = P.ncx * (((key.rows - 1) >> P.cell_log2) + 1);
+        P.cap = std::max(8, std::min(kPatchEnt, env_int("PIGO_PATCH_CAP", kPatchEnt)));
+        P.t_hand = std::max(1, env_int("PIGO_PATCH_TREE", 4));
+        const size_t nbk = (size_t)max_frames * P.nb;
+        P.acap = (uint32_t)std::min<size_t>(nbk, 0xffffffffu);
+        p->patch_lds = (size_t)(160 << 10) - 4096;  // static LDS of k_tail_patch: entries, group record
+        P.pix_bytes = (int32_t)(p->patch_lds - (size_t)kPatchHead * (kCodeStride + 64) * 4);
+        if (nbk * P.cap < (1ull << 31)) {
+            HIP_TRY(p->d_patch_ent.alloc(nbk * P.cap));
+            HIP_TRY(p->d_patch_bcount.alloc(nbk));
+            HIP_TRY(p->d_patch_active.alloc((size_t)8 * P.acap));
+            HIP_TRY(hipMemsetAsync(p->d_patch_bcount.p, 0, nbk * 4, bs.s));  // (k_tail_patch leaves every bucket it drains empty)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_tail_patch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->patch_lds));
+            P.ent = p->d_patch_ent.p;
+            P.bcount = p->d_patch_bcount.p;
+            P.active = p->d_patch_active.p;
+            P.nactive = nullptr;  // per run: the queue set's counters + 32
+            p->patch_ok = true;
+        }
+    }
 
     ScanArgs &a = p->args;
     a.scales = p->d_scales.p;
@@ -1217,8 +1249,25 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             aa.qcount = p.d_qcount.p;
             ab.queue = p.d_queue.p + half;
             ab.qcount = p.d_qcount.p + 16;
-            launch_tiles<ROT, GUARD>(p, aa, xcd_cap, sa, mark, true, 2);
-            launch_tail<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, sa, mark, p.tile_patch);
+            bool patched = false;
+            if constexpr (!ROT) {
+                if (p.patch_ok) {
+                    // the tile classes bin their survivors by position; k_tail_patch finishes them out of LDS patches (and drains
+                    // the survivor queues, which only hold the entries of overfull buckets then): no k_tail_deep for this set
+                    aa.patch = p.patch;
+                    aa.patch.nactive = p.d_qcount.p + 32;
+                    launch_tiles<ROT, GUARD>(p, aa, xcd_cap, sa, mark, true, 2);
+                    mark("tail_patch");
+                    ScanArgs pa = aa;
+                    pa.qcap = xcd_cap;
+                    k_tail_patch<<<256 * std::max(1, env_int("PIGO_PATCH_PER_CU", 1)), kPatchThreads, p.patch_lds, sa>>>(pa);
+                    patched = true;
+                }
+            }
+            if (!patched) {
+                launch_tiles<ROT, GUARD>(p, aa, xcd_cap, sa, mark, true, 2);
+                launch_tail<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, sa, mark, p.tile_patch);
+            }
             if (fork) (void)hipEventRecord(p.ev_join, p.side);
             launch_tiles<ROT, GUARD>(p, ab, xcd_cap, s, mark, true, 1);
             launch_tail<ROT, GUARD>(p, ab, xcd_cap, p.d_queue2.p + half2, (uint32_t)half2, s, mark);
@@ -1295,7 +1344,7 @@ pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame
     a.nframes = nframes;
     a.counts = d_counts;
     a.tail_wgs = std::max(8, std::min(256, 2048 / nframes));
-    if (variant >= 1) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)std::max(nframes, 32) * 4, s));
+    if (variant >= 1) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)std::max(nframes, 64) * 4, s));
 
     size_t ev = 0;
     static const bool sync_debug = env_int("PIGO_SYNC_DEBUG", 0) != 0;  // debugging aid: synchronise and report before every kernel
@@ -1451,8 +1500,8 @@ extern "C" pigo_status pigo_plan_status(pigo_plan *p)
     p->last_flags[2] = flags[2];
     if (flags[1]) return fail(PIGO_ERR_PANIC, "the reference would panic: pixel index out of range in classifyRotatedRegion (pigo.go:167-179)");
     if (flags[0])
-        return fail(PIGO_ERR_CAPACITY, "survivor queue overflow (%s%s%s)", (flags[0] & 1) ? "tile LDS queue " : "", (flags[0] & 2) ? "survivor queue " : "",
-                    (flags[0] & 4) ? "second-level tail queue" : "");
+        return fail(PIGO_ERR_CAPACITY, "survivor queue overflow (%s%s%s%s)", (flags[0] & 1) ? "tile LDS queue " : "", (flags[0] & 2) ? "survivor queue " : "",
+                    (flags[0] & 4) ? "second-level tail queue " : "", (flags[0] & 8) ? "bucket list" : "");
     if (flags[2]) return fail(PIGO_ERR_CAPACITY, "a frame has more than det_cap (%d) detections: its list is truncated (d_counts holds the true count)", p->det_cap);
     return PIGO_OK;
 }

