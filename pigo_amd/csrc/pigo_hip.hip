@@ -200,6 +200,7 @@ struct pigo_plan {
     DevBuf<QEntry> d_queue;
     DevBuf<uint32_t> d_qcount;
     DevBuf<int32_t> d_ties;              // per-frame tie counts when the caller does not ask for them
+    DevBuf<uint8_t> d_gosort_ws;         // k_gosort_ties: keys + tie counts of lists longer than kGoSortKeys
     // ClusterDetections for long lists (k_cluster_seeds / _members / _compact): seed lists, per-seed clusters before compaction
     DevBuf<int32_t> d_cl_seeds, d_cl_nseeds, d_cl_tmpn;
     DevBuf<pigo_det> d_cl_tmp;
@@ -978,7 +979,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     if (st != PIGO_OK) return st;
     // Variant 3, upright: the survivors of the rungs beyond the region groups are binned by position for k_tail_patch
     // (PIGO_PATCH=0: round 2's late mode + k_tail_deep instead).
-    if (p->region_ok && !p->rot && env_int("PIGO_PATCH", 1) != 0 && nscales <= 2047 && (int)c->ntrees >= kPatchHead) {
+    if (p->region_ok && !p->rot && env_int("PIGO_PATCH", 0) != 0 && nscales <= 2047 && (int)c->ntrees >= kPatchHead && c->ntrees <= 2048) {
         PatchArgs &P = p->patch;
         P.cell_log2 = std::max(4, std::min(8, env_int("PIGO_PATCH_CELL_LOG2", 6)));
         P.ncx = ((key.cols - 1) >> P.cell_log2) + 1;
@@ -988,7 +989,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         const size_t nbk = (size_t)max_frames * P.nb;
         P.acap = (uint32_t)std::min<size_t>(nbk, 0xffffffffu);
         p->patch_lds = (size_t)(160 << 10) - 4096;  // static LDS of k_tail_patch: entries, group record
-        P.pix_bytes = (int32_t)(p->patch_lds - (size_t)kPatchHead * (kCodeStride + 64) * 4);
+        P.pix_bytes = (int32_t)(p->patch_lds - (size_t)kPatchHead * (kCodeStride + 64) * 4 - (size_t)c->ntrees * 4 - (size_t)((c->ntrees + 7) & ~7u) * 2);
         if (nbk * P.cap < (1ull << 31)) {
             HIP_TRY(p->d_patch_ent.alloc(nbk * P.cap));
             HIP_TRY(p->d_patch_bcount.alloc(nbk));
@@ -1637,11 +1638,18 @@ extern "C" pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, c
     // seed order and the float32 sum order of ClusterDetections -- is the reference's
     {
         const int lds_keys = std::min(p->det_cap, kGoSortKeys);
+        const size_t lds_fixed = sizeof(gosort::PartList) + (size_t)(gosort::kSortThreads / 64) * 2 * gosort::kWaveFifo * 4;
         if (!p->gosort_attr) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_gosort_ties, hipFuncAttributeMaxDynamicSharedMemorySize, kGoSortKeys * 10));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_gosort_ties, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_fixed + (size_t)kGoSortKeys * 10)));
             p->gosort_attr = true;
         }
-        k_gosort_ties<<<nframes, 64, (size_t)lds_keys * 10, s>>>(d_dets, d_counts, p->det_cap, d_ties, d_sorted, lds_keys);
+        if (p->det_cap > kGoSortKeys) {  // lists that do not fit the LDS keep their keys and tie counts here
+            std::lock_guard<std::mutex> lock(p->mu);
+            const size_t need = (size_t)p->max_frames * p->det_cap * 12;
+            if (p->d_gosort_ws.n < need) HIP_TRY(p->d_gosort_ws.alloc(need));
+        }
+        k_gosort_ties<<<nframes, gosort::kSortThreads, lds_fixed + (size_t)lds_keys * 10, s>>>(d_dets, d_counts, p->det_cap, d_ties, d_sorted, lds_keys,
+                                                                                              p->det_cap > kGoSortKeys ? p->d_gosort_ws.p : nullptr);
     }
     if (v2) {
         k_cluster_seeds<<<nframes, kSeedThreads, 0, s>>>(d_sorted, d_counts, p->det_cap, iou_threshold, p->d_cl_seeds.p, p->d_cl_nseeds.p);

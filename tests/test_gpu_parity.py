@@ -280,6 +280,57 @@ def test_batch_clustering_is_tie_exact(pg, orc):
         assert_same_dets(cl[f], wc, f"tie-exact clusters frame {f}", Q_TOL_RAW)
 
 
+def test_batch_go_order_sort_of_long_lists(pg, orc):
+    """k_gosort_ties with one workgroup per frame (wave-parallel partitions, parts shared between the waves): lists of the 4K
+    stress config's length and beyond -- out of LDS (<= 14336 keys) and out of the global workspace (> 14336) -- with ties of
+    every density, already sorted / nearly sorted / descending inputs (partialInsertionSort, reverseRange, partitionEqual,
+    breakPatterns), next to short lists.  Sorted lists and clusters must equal the oracle's restatement of sort.Slice +
+    ClusterDetections (core/pigo.go:262-308)."""
+    import torch
+    from pigo_amd import batch
+    cap = 20000
+    rng = np.random.default_rng(11)
+    specs = [(13000, 50, "rand"), (18000, 7, "rand"), (14336, 2000, "rand"), (14337, 10**7, "onetie"), (6000, 300, "asc"), (6000, 300, "nearly"),
+             (5000, 40, "desc"), (9000, 1, "rand"), (64, 3, "rand"), (13, 2, "rand"), (12, 2, "rand"), (3000, 10**7, "rand")]
+    nfr = len(specs)
+    plan = batch.ScanPlan(pg, 240, 320, MinSize=20, MaxSize=200, ShiftFactor=0.1, ScaleFactor=1.1, max_frames=nfr, det_cap=cap)
+    lists = []
+    for n, levels, kind in specs:
+        rows = rng.integers(20, 30000, n)
+        cols = rng.integers(20, 30000, n)
+        scales = rng.integers(20, 400, n)
+        q = (rng.integers(1, levels + 1, n) / np.float32(3.0)).astype(np.float32)
+        if kind == "onetie":
+            q[rng.integers(0, n)] = q[rng.integers(0, n)]
+        if kind in ("asc", "nearly"):
+            q = np.sort(q)
+        if kind == "nearly":
+            for _ in range(4):
+                i, j = rng.integers(0, n, 2)
+                q[i], q[j] = q[j], q[i]
+        if kind == "desc":
+            q = np.sort(q)[::-1].copy()
+        d = np.zeros(n, dtype=core.DET_DTYPE)
+        d["row"], d["col"], d["scale"], d["q"] = rows, cols, scales, q
+        lists.append(d)
+    host = np.zeros((nfr, cap), dtype=core.DET_DTYPE)
+    for f, l in enumerate(lists):
+        host[f, : len(l)] = l
+    dets = torch.from_numpy(host.view(np.int32).reshape(nfr, cap, 4)).cuda()
+    counts = torch.tensor([len(l) for l in lists], dtype=torch.int32, device="cuda")
+    for rep in range(2):
+        sorted_, clusters, ccounts, ties = plan.cluster(dets, counts, 0.3)
+        torch.cuda.synchronize()
+        cl = batch.dets_to_numpy(clusters, ccounts)
+        srt = batch.dets_to_numpy(sorted_, counts)
+        for f, l in enumerate(lists):
+            w = _as_oracle(l)
+            wc, wties = orc.cluster_detections(w, 0.3, want_ties=True)
+            assert int(ties[f]) == wties, (f, specs[f])
+            assert_same_dets(srt[f], w, f"long sorted frame {f} {specs[f]}", Q_TOL_RAW)
+            assert_same_dets(cl[f], wc, f"long clusters frame {f} {specs[f]}", Q_TOL_RAW)
+
+
 @pytest.mark.parametrize("chunks,angle", [(2, 0.0), (3, 0.0), (1, 0.0), (0, 0.0), (2, 0.6)])
 def test_chunked_pipeline_large_batches(pg, orc, chunks, angle, monkeypatch):
     """Batches of >= 16 frames are cut into chunks whose deep tail overlaps the next chunk's tile kernels (two queue sets,
