@@ -479,6 +479,24 @@ def test_cpp_mirror_runs_on_gpu(tmp_path):
     assert r.returncode == 0 and "dets=4 clusters=1 (206,154,261," in r.stdout and "gray177=1" in r.stdout and "eye_ok=1" in r.stdout and "wire_ok=1" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
+def test_go_order_sort_program(tmp_path):
+    """tests/gosort_gpu_check.hip: k_sort_by_q + k_gosort_ties (wave-parallel pdqsort) against the host restatement of Go's
+    sort.Slice on 120 random lists -- every tie density, sorted / nearly sorted / descending inputs, lengths on both sides of
+    the LDS limit -- with one wave and with the production eight.  core/pigo.go:264-266."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "gosort_gpu_check")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", os.path.join(root, "tests", "gosort_gpu_check.hip"), "-o", exe])
+    for threads, trials in ((512, 12), (64, 3)):
+        r = subprocess.run([exe, str(threads), str(trials)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.startswith("ok threads=%d" % threads), (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
 # ---- the path bench.py times: many 1080p frames, chunked pipeline, side stream, per-XCD queues -----------------------------
 
 
