@@ -181,22 +181,35 @@ def cpu_baseline(args, frames, windows_per_frame):
     }
 
 
-def verify_against_oracle(args, frames, dets, counts, clusters, ccounts, k):
-    """Bit-exact check of the first k frames of the timed batch (raw RunCascade lists and clusters) against the CPU oracle,
-    one host thread per frame.  Raises on any difference: a fast wrong answer must not produce a bench line."""
+def verify_frame_indices(nframes, k):
+    """k frames of a batch to check: the first ceil(k/2) and the last floor(k/2) -- the head of the XCD dealing and its tail
+    (the `nframes % 8` remainder blocks of map_block, the last pipeline chunk)."""
+    k = min(k, nframes)
+    head = (k + 1) // 2
+    return sorted(set(range(head)) | set(range(nframes - (k - head), nframes)))
+
+
+def verify_against_oracle(args, frames, dets, counts, clusters, ccounts, k, what="batch"):
+    """Bit-exact check of k frames of the timed batch -- its first and its last ones (verify_frame_indices) -- raw RunCascade lists
+    and clusters, against the CPU oracle, one host thread per frame.  Raises on any difference: a fast wrong answer must not
+    produce a bench line.  Returns the frame indices checked."""
     import threading
     import oracle
     from pigo_amd import batch, synth
     orc = oracle.OraclePigo.unpack(synth.facefinder_bytes())
-    got = batch.dets_to_numpy(dets[:k], counts[:k])
-    gcl = batch.dets_to_numpy(clusters[:k], ccounts[:k]) if clusters is not None else None
+    idx = verify_frame_indices(len(frames), k)
+    sel = torch_index(idx, dets.device)
+    got = batch.dets_to_numpy(dets[sel], counts[sel])
+    gcl = batch.dets_to_numpy(clusters[sel], ccounts[sel]) if clusters is not None else None
+    k = len(idx)
     want, wantc = [None] * k, [None] * k
 
-    def work(f):
-        want[f] = orc.run_cascade(frames[f], args.rows, args.cols, args.cols, args.min_size, args.max_size, args.shift, args.scale, args.angle)
-        wantc[f] = orc.cluster_detections(want[f].copy(), args.iou)
+    def work(j):
+        f = idx[j]
+        want[j] = orc.run_cascade(frames[f], args.rows, args.cols, args.cols, args.min_size, args.max_size, args.shift, args.scale, args.angle)
+        wantc[j] = orc.cluster_detections(want[j].copy(), args.iou)
 
-    th = [threading.Thread(target=work, args=(f,)) for f in range(k)]
+    th = [threading.Thread(target=work, args=(j,)) for j in range(k)]
     for t in th:
         t.start()
     for t in th:
@@ -210,11 +223,16 @@ def verify_against_oracle(args, frames, dets, counts, clusters, ccounts, k):
                     np.float32(a[i]["q"]) != np.float32(b[i]["q"]):
                 raise SystemExit(f"bench.py: VERIFICATION FAILED: {what} record {i}: {a[i]} vs oracle {b[i]}")
 
-    for f in range(k):
-        same(got[f], want[f], f"frame {f} RunCascade")
+    for j in range(k):
+        same(got[j], want[j], f"{what} frame {idx[j]} RunCascade")
         if gcl is not None:
-            same(gcl[f], wantc[f], f"frame {f} ClusterDetections")
-    return k
+            same(gcl[j], wantc[j], f"{what} frame {idx[j]} ClusterDetections")
+    return idx
+
+
+def torch_index(idx, device):
+    import torch
+    return torch.tensor(idx, dtype=torch.long, device=device)
 
 
 def main():
@@ -315,10 +333,11 @@ def main():
         plan.status()
     if int(counts.max().item()) > args.det_cap:
         raise SystemExit(f"bench.py: a frame has {int(counts.max().item())} detections, det_cap is {args.det_cap}: truncated lists")
-    verified = 0
+    verified, verified_idx = 0, []
     if rank == 0 and args.verify_frames > 0:
-        verified = verify_against_oracle(args, frames, dets, counts, None if args.no_cluster else cl_out[1],
-                                         None if args.no_cluster else cl_out[2], min(args.verify_frames, B))
+        verified_idx = verify_against_oracle(args, frames, dets, counts, None if args.no_cluster else cl_out[1],
+                                             None if args.no_cluster else cl_out[2], min(args.verify_frames, B))
+        verified = len(verified_idx)
         if last is not None:  # rank 0's own rows of the gathered tensor are its cluster lists in wire format
             ref = distributed.pack_lists(dets if args.no_cluster else cl_out[1], counts if args.no_cluster else cl_out[2], gcap)
             if not torch.equal(last[:B], ref):
@@ -498,9 +517,14 @@ def main():
         planS.status()
         assert int(cntS.max().item()) <= args.det_cap
         assert torch.equal(cntS[:B], counts) and torch.equal(detS[:B], dets), "the shard's first frames must reproduce the default batch"
+        shard_checked = []
+        if args.verify_frames > 0:  # frames only the shard has (its last ones), against the CPU oracle
+            tail = S - 4
+            shard_checked = [tail + j for j in verify_against_oracle(args, fS[tail:], detS[tail:], cntS[tail:], clS[1][tail:], clS[2][tail:], 4, what="config-3 shard tail")]
         shard_leg = {"frames_per_gpu": S, "ms_per_step": round(msS, 3), "mwindows_per_s": round(S * int(info.windows_per_frame) / msS / 1e3, 1),
                      "frames_per_s": round(S / msS * 1e3, 1), "resident_bytes": int(fS.nbytes), "detections": int(cntS.sum().item()),
-                     "note": "BASELINE configs[2] per-GPU shard (8192 frames / 8 GPUs); first frames compared with the default batch"}
+                     "verified_frames": shard_checked,
+                     "note": "BASELINE configs[2] per-GPU shard (8192 frames / 8 GPUs); its first frames compared with the default batch, its last four with the CPU oracle"}
         del planS, dS, detS, cntS, clS, fS
 
     if rank == 0:
@@ -514,14 +538,22 @@ def main():
         dom = {3: "scan_region+scan_tile+tail_deep", 2: "scan_tile+tail_deep", 1: "scan_head+scan_tail", 0: "scan_mono"}.get(int(info.variant), "scan")
         alg_bytes = B * args.rows * args.cols + 16 * ndet  # every frame read once + 16 B per emitted detection
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms else None
-        # HBM traffic: PMC counters cannot be read live; the committed profile of the same workload (separate rocprofv3
-        # --pmc passes, profiles/r01_traffic.json) gives bytes per frame, scaled here to this batch
-        traffic = None
-        tname = {3: "r02_traffic.json", 2: "r01_traffic.json"}.get(int(info.variant))
+        # Memory traffic of the scan kernels: PMC counters cannot be read live; the committed profile of the same workload
+        # (separate rocprofv3 --pmc passes, profiles/rNN_traffic.json) gives FABRIC-side bytes per frame -- what the L2s missed,
+        # Infinity-Cache hits included -- scaled here to this batch.  It is an upper bound of the HBM bytes.
+        traffic, tnote = None, None
+        tname = {3: "r03_traffic.json", 2: "r01_traffic.json"}.get(int(info.variant))
         tpath = os.path.join(ROOT, "profiles", tname) if tname else None
+        if tpath and not os.path.exists(tpath) and int(info.variant) == 3:
+            tname = "r02_traffic.json"
+            tpath = os.path.join(ROOT, "profiles", tname)
         if tpath and os.path.exists(tpath) and (args.rows, args.cols, args.kind, args.angle) == (1080, 1920, "faces", 0.0):
             with open(tpath) as fh:
-                traffic = int(json.load(fh)["hbm_bytes_per_frame"]) * B
+                trec = json.load(fh)
+            traffic = int(trec.get("fabric_bytes_per_frame", trec.get("hbm_bytes_per_frame"))) * B
+            tnote = (f"profiled offline (profiles/{tname}): L2-miss (fabric-side) bytes of the scan kernels = 2 x FETCH_SIZE + WRITE_SIZE per frame, "
+                     "separate rocprofv3 --pmc passes, x frames; FETCH_SIZE x 2 agrees with TCC_MISS_sum x 128 B on these byte gathers; "
+                     "includes Infinity-Cache hits (a 128-frame batch is 265 MB), so an upper bound of the HBM bytes")
         out = {
             "metric": "Mwindows/s (1080p facefinder scan, shift 0.1 / scale 1.1)" if (args.rows, args.cols) == (1080, 1920) else "Mwindows/s",
             "value": round(fps * wpf / 1e6, 3),
@@ -544,7 +576,8 @@ def main():
                                + (f"; one all-gather per step via {gather_mode}" if use_dist else ""),
             },
             "verified_frames": verified,
-            "verification": "first frames of the timed batch vs the CPU oracle, raw lists and clusters bit-exact (q 0 ulp); counts.max() <= det_cap"
+            "verified_frame_indices": verified_idx,
+            "verification": "the first and the last frames of the timed batch vs the CPU oracle, raw lists and clusters bit-exact (q 0 ulp); counts.max() <= det_cap"
                             + ("; rank 0's gathered rows vs its lists; one frame of the last rank through the all-gather" if use_dist else ""),
             "gather": gather_mode,
             "kernel_ms_schedule": "per-kernel HIP-event times are taken with the chunked pipeline and the side stream OFF (each launch alone on "
@@ -556,7 +589,7 @@ def main():
                 "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                 "traffic": traffic,
-                "traffic_note": f"profiled offline (profiles/{tname}: 2 x FETCH_SIZE + WRITE_SIZE per frame of the scan kernels, separate rocprofv3 --pmc passes) x frames" if traffic else None,
+                "traffic_note": tnote,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "compulsory bytes only (each frame read once + 16 B per detection); the scan is not bound by HBM: the region kernel by its "
                         "waves' dependent VALU->LDS chains (LDS pipe ~54 % busy, ~44 % of that bank conflicts), the 1 % largest windows by the "

@@ -176,7 +176,6 @@ struct pigo_plan {
     std::vector<RegionGroup> regions;
     bool region_ok = false;
     bool tile_patch = true;              // variant 3: do the tile classes' survivors include scales <= kPatchMaxS?
-    bool sparse_mode = true;             // variant 3: rungs beyond the region groups by k_scan_sparse (else k_scan_tile + k_tail_deep)
     DevBuf<uint32_t> d_tabr;
     // variant 3, rungs beyond the region groups: survivors binned by position for k_tail_patch
     bool patch_ok = false;
@@ -184,9 +183,6 @@ struct pigo_plan {
     size_t patch_lds = 0;
     DevBuf<uint4> d_patch_ent;
     DevBuf<uint32_t> d_patch_bcount, d_patch_active;
-    // variant 3, rungs beyond the region groups: k_scan_sparse, one wave per 64 consecutive windows {rung, first window}
-    std::vector<uint2> sparse_groups;
-    DevBuf<uint2> d_sparse;
     DevBuf<uint32_t> d_tabp;
     bool tile_ok = false;
     int tab_lds = 0, tab_glb = 0;        // LDS table capacity (trees) of the LDS-pixel / global-pixel classes
@@ -704,7 +700,7 @@ bool build_region_groups(pigo_plan &p)
     const int pool_cap = kRegWavePool;
     // leaves + raw codes of the nh trees, per wave a queue of kRegWaveChunk 6-byte and a pool of kRegWavePool 8-byte entries;
     // plus, per group, the offset tables of the chunk-stage trees of every scale of the group
-    constexpr int NG = 3;  // scale groups: small, mid, big (the big group only when PIGO_REG_S2 names its largest scale)
+    constexpr int NG = 3;  // scale groups: small, mid (a third one was measured and loses: profiles/r02_experiments.md; its slot stays empty)
     const int chunkg[NG] = {std::min(kRegWaveChunk, std::max(64, env_int("PIGO_REG_CHUNK0", 512) & ~63)),
                             std::min(kRegWaveChunk, std::max(64, env_int("PIGO_REG_CHUNK1", 128) & ~63)),
                             std::min(kRegWaveChunk, std::max(64, env_int("PIGO_REG_CHUNK2", 64) & ~63))};
@@ -713,7 +709,7 @@ bool build_region_groups(pigo_plan &p)
     const int deepg[NG] = {std::max(64, env_int("PIGO_REG_DEEP0", 1024)), std::max(64, env_int("PIGO_REG_DEEP1", 512)), std::max(64, env_int("PIGO_REG_DEEP2", 256))};
     const size_t max_dyn = (size_t)(160 << 10) - 3072;  // static LDS of k_scan_region: per-scale geometry, counters, thresholds
     // (group limits: 51 / 148 measured best after the deep list got cheaper -- 42…51 / 148 within 0.3 %, 62 / 135 3 % slower)
-    const int smax[NG] = {env_int("PIGO_REG_S0", 51), env_int("PIGO_REG_S1", 148), env_int("PIGO_REG_S2", 0)};
+    const int smax[NG] = {env_int("PIGO_REG_S0", 51), env_int("PIGO_REG_S1", 148), 0};
     const int cwmax[NG] = {env_int("PIGO_REG_CW0", 320), env_int("PIGO_REG_CW1", 192), env_int("PIGO_REG_CW2", 128)};
     int k = 0;
     const int nscales = (int)p.scales.size();
@@ -792,11 +788,6 @@ bool build_region_groups(pigo_plan &p)
 #undef REG_BAIL
     if (p.regions.empty()) return false;
     const int kbig = p.regions.back().args.k_hi;
-    p.sparse_groups.clear();
-    for (int j = kbig; j < nscales; ++j) {
-        const long long nw = (long long)p.scales[j].nr * p.scales[j].nc;
-        for (long long f0 = 0; f0 < nw; f0 += 64) p.sparse_groups.push_back(make_uint2((unsigned)j, (unsigned)f0));
-    }
     for (pigo_plan::TileClass &cls : p.classes) {
         cls.v3_skip = 0;
         for (uint32_t t = 0; t < cls.ntiles; ++t)
@@ -947,7 +938,6 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         // eager launches (profiles/r02_experiments.md); PIGO_GRAPH_FRAMES=n turns it on for batches of up to n frames
         p->graph_max_frames = std::max(0, env_int("PIGO_GRAPH_FRAMES", 0));
         p->region_ok = build_region_groups(*p);
-        p->sparse_mode = env_int("PIGO_SPARSE", 0) != 0;  // (measured: 10x slower than the tile classes -- uncompacted byte gathers; kept as an A/B switch)
         if (p->region_ok) {
             // the region groups' offset tables: k_build_tabp with every rung's pitch set to its group's region pitch
             std::vector<ScaleDesc> sreg(p->scales);
@@ -964,11 +954,6 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
             HIP_TRY(hipStreamSynchronize(bs.s));  // (before sreg / d_sreg go out of scope)
             HIP_TRY(hipFuncSetAttribute((const void *)k_scan_region<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 3072));
             HIP_TRY(hipFuncSetAttribute((const void *)k_scan_region<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 3072));
-            if (!p->sparse_groups.empty()) {
-                HIP_TRY(p->d_sparse.alloc(p->sparse_groups.size()));
-                HIP_TRY(hipMemcpyAsync(p->d_sparse.p, p->sparse_groups.data(), p->sparse_groups.size() * sizeof(uint2), hipMemcpyHostToDevice, bs.s));
-                HIP_TRY(hipStreamSynchronize(bs.s));
-            }
         }
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
@@ -986,10 +971,12 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         P.nb = P.ncx * (((key.rows - 1) >> P.cell_log2) + 1);
         P.cap = std::max(8, std::min(kPatchEnt, env_int("PIGO_PATCH_CAP", kPatchEnt)));
         P.t_hand = std::max(1, env_int("PIGO_PATCH_TREE", 4));
+        P.nscales = nscales;
         const size_t nbk = (size_t)max_frames * P.nb;
         P.acap = (uint32_t)std::min<size_t>(nbk, 0xffffffffu);
         p->patch_lds = (size_t)(160 << 10) - 4096;  // static LDS of k_tail_patch: entries, group record
-        P.pix_bytes = (int32_t)(p->patch_lds - (size_t)kPatchHead * (kCodeStride + 64) * 4 - (size_t)c->ntrees * 4 - (size_t)((c->ntrees + 7) & ~7u) * 2);
+        P.pix_bytes = (int32_t)(p->patch_lds - (size_t)kPatchHead * (kCodeStride + 64) * 4 - (size_t)c->ntrees * 4 - (size_t)((c->ntrees + 7) & ~7u) * 2 -
+                                (size_t)((nscales + 7) & ~7) * 2);
         if (nbk * P.cap < (1ull << 31)) {
             HIP_TRY(p->d_patch_ent.alloc(nbk * P.cap));
             HIP_TRY(p->d_patch_bcount.alloc(nbk));
@@ -1065,7 +1052,7 @@ template <bool ROT, bool GUARD, class Mark>
 void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipStream_t s, Mark &mark, bool v3 = false, int what = 3)
 {
     // variant 3: the region kernel scans the rungs of its scale groups, k_scan_tile only what lies beyond them
-    // (what & 1: the region / sparse launches, what & 2: the tile classes)
+    // (what & 1: the region launches, what & 2: the tile classes)
 #ifdef PIGO_DEBUG_BUILD
     if (v3 && env_int("PIGO_REG_ONLY", -1) >= 0) what &= 1;
 #endif
@@ -1095,14 +1082,6 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
             (void)hipEventRecord(p.ev_gjoin, p.grp_stream);
             (void)hipStreamWaitEvent(s, p.ev_gjoin, 0);
         }
-        if (p.sparse_mode && !p.sparse_groups.empty()) {
-            ScanArgs sa = a;
-            sa.reg = p.regions.front().args;  // (nh)
-            const uint32_t ng = (uint32_t)p.sparse_groups.size();
-            mark("scan_sparse");
-            k_scan_sparse<<<(uint32_t)a.nframes * ((ng + 3u) / 4u), 256, 0, s>>>(sa, p.d_sparse.p, ng);
-        }
-        if (p.sparse_mode) return;  // every window of the frame is covered: no tile classes
     }
     if (!(what & 2)) return;
     // fork: classes that gather from global memory go to the side stream when the plan also has LDS-tile classes
@@ -1230,9 +1209,8 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
         const bool v3 = variant == 3;
         const long long qtotal = p.qcap * (long long)p.max_frames;  // entries of d_queue
         const int want_chunks = p.pipe_chunks > 0 ? p.pipe_chunks : std::max(2, std::min(8, (a.nframes + 31) / 32));
-        // (variant 3 with the sparse kernel finishes every window inside its own launches: nothing to overlap, one chunk)
         const int chunks = (p.tail_stream && !p.profiling && a.nframes >= 16 && a.deep_lo < a.ntrees && !v3) ? want_chunks : 1;
-        if (v3 && !p.sparse_mode && a.deep_lo < a.ntrees) {
+        if (v3 && a.deep_lo < a.ntrees) {
             // Variant 3: the region launches (LDS-bound, they keep every window of their scales to themselves) on `s`, the tile
             // classes of the big scales and their deep tail (vector-memory / latency bound) next to them on the side stream.
             // Two queue sets: A for the tile classes, B for the (rare) spill of the regions' deep lists.

@@ -1,0 +1,27 @@
+# Round-3 measurement: parity suite, smoke, the default bench line, the other configs, rocprofv3 trace + PMC passes, RCCL trace
+mkdir -p gpurun_out/prof_r3f && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/prof_r3f
+nproc > $O/host.txt; (rocminfo | grep -m3 "Marketing Name" ) >> $O/host.txt 2>&1
+if [ -z "$SKIP_PYTEST" ]; then timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log | cut -c1-200; fi
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; cut -c1-500 $O/bench_default.json; tail -2 $O/bench_default.err
+timeout 300 python bench.py --kind noise --no-cpu-baseline --no-gray --shard-frames 0 > $O/bench_noise.json 2> $O/bench_noise.err; echo "noise rc=$?"; cut -c1-200 $O/bench_noise.json
+timeout 300 python bench.py --angle 0.8 --no-cpu-baseline --no-gray --shard-frames 0 > $O/bench_rot.json 2> $O/bench_rot.err; echo "rot rc=$?"; cut -c1-200 $O/bench_rot.json
+timeout 300 python bench.py --rows 2160 --cols 3840 --min-size 20 --max-size 2000 --shift 0.05 --scale 1.05 --frames 8 --det-cap 32768 --gather-cap 64 --steps 5 --warmup 2 --no-cpu-baseline --no-gray --shard-frames 0 --verify-frames 2 > $O/bench_4k.json 2> $O/bench_4k.err; echo "4k rc=$?"; cut -c1-200 $O/bench_4k.json; tail -2 $O/bench_4k.err
+timeout 300 python bench.py --frames 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gray --shard-frames 0 --verify-frames 1 --no-single-frame > $O/bench_1frame.json 2> $O/bench_1frame.err; echo "1frame rc=$?"; cut -c1-300 $O/bench_1frame.json
+python scripts/single_frame_latency.py 2>&1 | grep "single 1080p" | tee $O/single_frame.txt
+# the C ABI's collective at world size 1 through a real RCCL communicator, with a kernel trace that shows the RCCL kernel
+D="python bench.py --force-dist --frames 32 --steps 3 --warmup 1 --no-cpu-baseline --no-gray --shard-frames 0"
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_dist -o t -- $D > $O/bench_dist1.log 2>&1; echo "dist1 rc=$?"; grep '"metric"' $O/bench_dist1.log > $O/bench_dist1.json; cut -c1-200 $O/bench_dist1.json
+python scripts/summarize_prof.py "world-size-1 RCCL run (pigo_run_batch_sharded, communicator built with ncclGetUniqueId / ncclCommInitRank): $D" $O/trace_dist/t_results.db > $O/dist1_trace_summary.txt 2>&1; grep -i -E "nccl|rccl|k_pack" $O/dist1_trace_summary.txt | cut -c1-140
+B="env PIGO_SIDE_STREAM=0 python bench.py --frames 64 --steps 5 --warmup 2 --no-cpu-baseline --no-single-frame --shard-frames 0 --verify-frames 0"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- $B > $O/trace.log 2>&1; echo "trace rc=$?"
+timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- $B > $O/pmc_fetch.log 2>&1; echo "pmc_fetch rc=$?"
+timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o p -- $B > $O/pmc_write.log 2>&1; echo "pmc_write rc=$?"
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum -d $O/pmc_tcc -o p -- $B > $O/pmc_tcc.log 2>&1; echo "pmc_tcc rc=$?"
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pmc_sq -o p -- $B > $O/pmc_sq.log 2>&1; echo "pmc_sq rc=$?"
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $O/pmc_sq2 -o p -- $B > $O/pmc_sq2.log 2>&1; echo "pmc_sq2 rc=$?"
+python scripts/summarize_prof.py "round 3 final (scripts/gpu_round3_final.sh): $B -- 64 x 1080p SYN-FACES frames per step; 12 scan steps per run (2 warm-up + 5 timed + 5 per-kernel event reps); PIGO_SIDE_STREAM=0 puts the tile classes of the big scales and their deep tail behind the region launches on ONE stream so that every launch is un-overlapped like bench.py's kernel_ms (the timed default runs them next to the region launches on a side stream)" $O/trace/t_results.db $O/pmc_fetch/p_results.db $O/pmc_write/p_results.db $O/pmc_tcc/p_results.db $O/pmc_sq/p_results.db $O/pmc_sq2/p_results.db > $O/final_summary.txt 2>$O/final_summary.err; echo "summary rc=$?"; head -16 $O/final_summary.txt | cut -c1-150
+python scripts/make_traffic.py $O/pmc_fetch/p_results.db $O/pmc_write/p_results.db 12 64 $O/pmc_tcc/p_results.db > $O/traffic.json 2>$O/traffic.err; echo "traffic rc=$?"; grep -E "fabric_bytes_per_frame\"|hit_rate" $O/traffic.json
+rm -rf $O/trace $O/trace_dist $O/pmc_fetch $O/pmc_write $O/pmc_tcc $O/pmc_sq $O/pmc_sq2
+du -sh $O

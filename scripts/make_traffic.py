@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""profiles/r01_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_round1_final.sh.
+"""profiles/rNN_traffic.json from the FETCH_SIZE / WRITE_SIZE (and, optionally, TCC_HIT / TCC_MISS) passes of the round's final script.
 
-    python scripts/make_traffic.py <pmc_fetch.db> <pmc_write.db> <steps in the profiled run> <frames per step>
+    python scripts/make_traffic.py <pmc_fetch.db> <pmc_write.db> <steps in the profiled run> <frames per step> [<pmc_tcc.db>]
 
-HBM bytes per frame of the scan kernels (k_scan_tile*, k_tail_deep*) = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / frames:
-FETCH_SIZE is doubled per the gfx950 note of MI355X_MICROARCH.md (rocprofv3 reports half of a wide coalesced stream; for
-this kernel's 4-byte-per-lane copies that is an upper bound), WRITE_SIZE is taken as reported.
+Fabric-side (L2-miss) bytes per frame of the scan kernels = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / frames: FETCH_SIZE is
+doubled per the gfx950 note of MI355X_MICROARCH.md; on this path's byte gathers 2 x FETCH_SIZE equals TCC_MISS_sum x 128 B
+(profiles/r03_pmc_l2.txt), so the factor holds here.  The figure includes Infinity-Cache hits: it bounds the HBM bytes from above.
 """
 import json
 import sqlite3
@@ -24,6 +24,7 @@ def per_step(db, counter, steps):
 
 def main():
     fetch_db, write_db, steps, frames = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    tcc_db = sys.argv[5] if len(sys.argv) > 5 else None
     f, w = per_step(fetch_db, "FETCH_SIZE", steps), per_step(write_db, "WRITE_SIZE", steps)
     scan = lambda d: sum(v["kib_per_step"] for k, v in d.items() if k.startswith("k_scan") or k.startswith("k_tail"))  # noqa: E731
     fk, wk = scan(f), scan(w)
@@ -33,11 +34,23 @@ def main():
         "frames_per_step": frames, "steps_in_profiled_run": steps,
         "fetch_kib_per_step": round(fk, 1), "write_kib_per_step": round(wk, 1),
         "correction": "FETCH_SIZE doubled (gfx950 rocprofv3 note; upper bound for 4 B/lane copies), WRITE_SIZE as reported",
-        "hbm_bytes_per_frame": int((2 * fk + wk) * 1024 / frames),
-        "hbm_bytes_per_frame_uncorrected": int((fk + wk) * 1024 / frames),
+        "fabric_bytes_per_frame": int((2 * fk + wk) * 1024 / frames),
+        "fabric_bytes_per_frame_uncorrected": int((fk + wk) * 1024 / frames),
+        "note": "L2-miss traffic as seen on the fabric side of the L2s; Infinity-Cache hits are included, so this bounds the HBM bytes from above",
         "breakdown_fetch_kib_per_step": {k: round(v["kib_per_step"], 1) for k, v in sorted(f.items()) if k.startswith(("k_scan", "k_tail", "k_restore", "k_sort", "k_cluster"))},
         "breakdown_write_kib_per_step": {k: round(v["kib_per_step"], 1) for k, v in sorted(w.items()) if k.startswith(("k_scan", "k_tail", "k_restore", "k_sort", "k_cluster"))},
     }
+    if tcc_db:
+        cur = sqlite3.connect(tcc_db).cursor()
+        l2 = {}
+        q = "select kernel_name, counter_name, sum(value) from counters_collection where counter_name in ('TCC_HIT_sum', 'TCC_MISS_sum') group by kernel_name, counter_name"
+        for name, cname, tot in cur.execute(q):
+            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            if short.startswith(("k_scan", "k_tail")):
+                l2.setdefault(short, {})[cname] = tot / steps
+        rec["l2_per_step"] = {k: {"hits": round(v.get("TCC_HIT_sum", 0)), "misses": round(v.get("TCC_MISS_sum", 0)),
+                                  "hit_rate": round(v.get("TCC_HIT_sum", 0) / max(1.0, v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0)), 4),
+                                  "miss_bytes_128": round(v.get("TCC_MISS_sum", 0) * 128)} for k, v in sorted(l2.items())}
     print(json.dumps(rec, indent=1))
 
 
