@@ -1611,7 +1611,14 @@ extern "C" pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, c
     if (!d_ties) d_ties = p->d_ties.p;
     HIP_TRY(hipMemsetAsync(d_ties, 0, (size_t)nframes * 4, s));
     dim3 grid((unsigned)((p->det_cap + kThreads - 1) / kThreads), (unsigned)nframes);
-    k_sort_by_q<<<grid, kThreads, 0, s>>>(d_dets, d_counts, p->det_cap, d_sorted, d_ties);
+    if (v2) {  // long lists: partial ranks over kRankSegs segments of the list, then one scatter (the rank array is d_cl_tmpn, free until the sweep)
+        uint32_t *d_rank = reinterpret_cast<uint32_t *>(p->d_cl_tmpn.p);
+        HIP_TRY(hipMemsetAsync(d_rank, 0, (size_t)nframes * p->det_cap * 4, s));
+        k_rank_partial<<<dim3(grid.x, kRankSegs, (unsigned)nframes), kThreads, 0, s>>>(d_dets, d_counts, p->det_cap, d_rank);
+        k_scatter_by_rank<<<grid, kThreads, 0, s>>>(d_dets, d_counts, p->det_cap, d_rank, d_sorted, d_ties);
+    } else {
+        k_sort_by_q<<<grid, kThreads, 0, s>>>(d_dets, d_counts, p->det_cap, d_sorted, d_ties);
+    }
     // frames with tied Q values: redo the sort with Go's own (unstable) algorithm so that the tie order -- and with it the
     // seed order and the float32 sum order of ClusterDetections -- is the reference's
     {
