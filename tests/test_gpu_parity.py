@@ -500,6 +500,61 @@ def test_go_order_sort_program(tmp_path):
 # ---- the path bench.py times: many 1080p frames, chunked pipeline, side stream, per-XCD queues -----------------------------
 
 
+def test_rotated_region_kernel_on_frames_with_rotated_faces(pg, orc):
+    """The rotated scan of frames whose faces ARE rotated the way angle 0.8 looks for them (the benchmark's upright faces leave a
+    rotated scan with a handful of detections per batch): hundreds of survivors per frame go through the rotated region
+    kernel's pool, deep lists and the big scales' tail.  12 frames (variant 3: >= 8), every frame against the oracle;
+    classifyRotatedRegion, core/pigo.go:150-191."""
+    import threading
+    import torch
+    from scipy import ndimage
+    from pigo_amd import batch
+    n, rows, cols, angle = 12, 720, 1280, 0.8
+    patch = synth.sample_gray()
+    rot = {z: ndimage.rotate(ndimage.zoom(patch, z, order=1) if z != 1.0 else patch, -79.0, reshape=True, order=1, mode="nearest") for z in (0.5, 1.0, 1.6)}
+    rng = np.random.default_rng(21)
+    frames = np.empty((n, rows, cols), dtype=np.uint8)
+    for f in range(n):
+        bg = synth.syn_noise((rows + 7) // 8, (cols + 7) // 8, seed=77, frame_index=f)
+        img = np.repeat(np.repeat(bg, 8, axis=0), 8, axis=1)[:rows, :cols].copy()
+        for _ in range(5):
+            p = rot[(0.5, 1.0, 1.0, 1.6)[int(rng.integers(0, 4))]]
+            ph, pw = p.shape
+            if ph > rows or pw > cols:
+                continue
+            r0, c0 = int(rng.integers(0, rows - ph + 1)), int(rng.integers(0, cols - pw + 1))
+            img[r0:r0 + ph, c0:c0 + pw] = p
+        frames[f] = img
+    want = [None] * n
+
+    def work(f):
+        want[f] = orc.run_cascade(frames[f], rows, cols, cols, 20, 700, 0.1, 1.1, angle)
+
+    th = [threading.Thread(target=work, args=(f,)) for f in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert sum(len(w) for w in want) > 100, [len(w) for w in want]  # the rotated faces are found
+    plan = batch.ScanPlan(pg, rows, cols, MinSize=20, MaxSize=700, ShiftFactor=0.1, ScaleFactor=1.1, angle=angle, max_frames=n, det_cap=4096)
+    assert plan.info().variant == 3
+    d_frames = torch.from_numpy(frames).cuda()
+    dets, counts = plan.alloc_outputs(n)
+    for rep in range(2):
+        plan.run(d_frames, dets, counts)
+        torch.cuda.synchronize()
+        plan.status()
+        got = batch.dets_to_numpy(dets, counts)
+        for f in range(n):
+            assert_same_dets(got[f], want[f], f"rotated faces frame {f} rep {rep}", Q_TOL_RAW)
+    plan.set_variant(2)
+    plan.run(d_frames, dets, counts)
+    torch.cuda.synchronize()
+    got = batch.dets_to_numpy(dets, counts)
+    for f in range(n):
+        assert_same_dets(got[f], want[f], f"rotated faces frame {f} variant 2", Q_TOL_RAW)
+
+
 @pytest.mark.parametrize("chunks,angle", [(0, 0.0), (4, 0.0), (0, 0.8)])
 def test_benchmarked_path_1080p_batch_against_oracle(pg, orc, chunks, angle, monkeypatch):
     """ScanPlan.run + plan.cluster on 40 x 1080p frames (faces + noise mix) exactly as bench.py drives them -- default
