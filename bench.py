@@ -65,6 +65,7 @@ def parse_args():
     ap.add_argument("--no-gray", action="store_true", help="skip the side measurements (RgbToGrayscale, RunDetector, single frame)")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call leg (keeps kernel profiles per-batch)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto, ~15 s)")
+    ap.add_argument("--face-rotation", type=float, default=0.0, help="rotate the pasted face patches by this many degrees (-79: what a scan at --angle 0.8 detects)")
     ap.add_argument("--verify-frames", type=int, default=8, help="frames of the timed batch checked against the CPU oracle afterwards")
     ap.add_argument("--gather", choices=["cabi", "torch"], default="cabi",
                     help="N > 1: all-gather through the C ABI (pigo_run_batch_sharded -> ncclAllGather) or torch.distributed")
@@ -262,7 +263,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     B = args.frames
-    frames = synth.make_frames(args.kind, B, args.rows, args.cols, seed=args.seed, first_index=rank * B)
+    frames = synth.make_frames(args.kind, B, args.rows, args.cols, seed=args.seed, first_index=rank * B, rotate_deg=args.face_rotation)
     d_frames = torch.from_numpy(frames).to(dev)
 
     pg = core.NewPigo(local_rank).Unpack(synth.facefinder_bytes())
@@ -344,7 +345,7 @@ def main():
                 raise SystemExit("bench.py: VERIFICATION FAILED: gathered rows of rank 0 differ from its lists")
             if world > 1:  # ... and a frame scanned by ANOTHER rank, as it arrived through the all-gather, against the oracle
                 import oracle
-                fo = synth.make_frames(args.kind, 1, args.rows, args.cols, seed=args.seed, first_index=(world - 1) * B)[0]
+                fo = synth.make_frames(args.kind, 1, args.rows, args.cols, seed=args.seed, first_index=(world - 1) * B, rotate_deg=args.face_rotation)[0]
                 orc = oracle.OraclePigo.unpack(synth.facefinder_bytes())
                 w = orc.run_cascade(fo, args.rows, args.cols, args.cols, args.min_size, args.max_size, args.shift, args.scale, args.angle)
                 if not args.no_cluster:
@@ -496,7 +497,7 @@ def main():
     shard_leg = None
     if side_legs and args.shard_frames > B and (args.rows, args.cols) == (1080, 1920):
         S = args.shard_frames
-        fS = synth.make_frames(args.kind, S, args.rows, args.cols, seed=args.seed, first_index=0)
+        fS = synth.make_frames(args.kind, S, args.rows, args.cols, seed=args.seed, first_index=0, rotate_deg=args.face_rotation)
         dS = torch.from_numpy(fS).to(dev)
         planS = batch.ScanPlan(pg, args.rows, args.cols, MinSize=args.min_size, MaxSize=args.max_size, ShiftFactor=args.shift,
                                ScaleFactor=args.scale, angle=args.angle, max_frames=S, det_cap=args.det_cap)
@@ -565,7 +566,7 @@ def main():
             "data": "synthetic",
             "frames_per_s": round(fps, 2),
             "config": {
-                "workload": f"{args.cols}x{args.rows} synthetic gray frames (SYN-{args.kind.upper()}, seed {args.seed}), facefinder cascade, "
+                "workload": f"{args.cols}x{args.rows} synthetic gray frames (SYN-{args.kind.upper()}, seed {args.seed}" + (f", faces rotated by {args.face_rotation} deg" if args.face_rotation else "") + "), facefinder cascade, "
                             f"MinSize={args.min_size} MaxSize={args.max_size} Shift={args.shift} Scale={args.scale} angle={args.angle}; "
                             f"{B} HBM-resident frames per GPU per step; RunCascade + per-frame ClusterDetections(iou={args.iou})"
                             + (f" + RCCL all-gather of {gcap}-record cluster lists" if use_dist else ""),

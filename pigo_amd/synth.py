@@ -54,13 +54,18 @@ def facefinder_bytes() -> bytes:
         return f.read()
 
 
-def syn_faces(rows: int, cols: int, seed: int = 1234, frame_index: int = 0, n_faces: int = None) -> np.ndarray:
-    """uint8 [rows, cols]: block-noise background + pasted face patches (see module docstring)."""
+def syn_faces(rows: int, cols: int, seed: int = 1234, frame_index: int = 0, n_faces: int = None, rotate_deg: float = 0.0) -> np.ndarray:
+    """uint8 [rows, cols]: block-noise background + pasted face patches (see module docstring).  rotate_deg != 0: the patch is
+    rotated first (scipy.ndimage.rotate, bilinear, reshape) -- -79 degrees is what a scan at angle 0.8 detects, so that the
+    rotated path is benchmarked with as many survivors as the upright one (bench.py --face-rotation)."""
     fs = _frame_seed(seed, frame_index)
     br, bc = (rows + 7) // 8, (cols + 7) // 8
     coarse = _splitmix64_block(fs ^ 0xA5A5A5A5, (br * bc + 7) // 8).view(np.uint8)[: br * bc].reshape(br, bc)
     img = np.repeat(np.repeat(coarse, 8, axis=0), 8, axis=1)[:rows, :cols].copy()
     patch = sample_gray()
+    if rotate_deg != 0.0:
+        from scipy import ndimage
+        patch = ndimage.rotate(patch, rotate_deg, reshape=True, order=1, mode="nearest")
     if n_faces is None:
         n_faces = max(1, int(round(18 * (rows * cols) / (1080.0 * 1920.0))))
     rnd = _splitmix64_block(fs ^ 0x5EED5EED, 3 * n_faces)
@@ -82,12 +87,11 @@ def syn_faces(rows: int, cols: int, seed: int = 1234, frame_index: int = 0, n_fa
     return img
 
 
-def make_frames(kind: str, n: int, rows: int, cols: int, seed: int = 1234, first_index: int = 0) -> np.ndarray:
+def make_frames(kind: str, n: int, rows: int, cols: int, seed: int = 1234, first_index: int = 0, rotate_deg: float = 0.0) -> np.ndarray:
     """uint8 [n, rows, cols] batch; frame f uses frame_index first_index + f."""
-    gen = {"noise": syn_noise, "faces": syn_faces}[kind]
     out = np.empty((n, rows, cols), dtype=np.uint8)
     for f in range(n):
-        out[f] = gen(rows, cols, seed, first_index + f)
+        out[f] = syn_noise(rows, cols, seed, first_index + f) if kind == "noise" else syn_faces(rows, cols, seed, first_index + f, rotate_deg=rotate_deg)
     return out
 
 
