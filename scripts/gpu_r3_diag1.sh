@@ -2,6 +2,7 @@
 # (4) the round-2 abort reproduced without the build mutex under rocgdb
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r3; mkdir -p $O
+[ -x scripts/micro/ta_gather ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/micro/ta_gather.hip -o scripts/micro/ta_gather
 timeout 300 scripts/micro/ta_gather 2000 > $O/ta_gather.txt 2>&1; echo "ta_gather rc=$?"; head -3 $O/ta_gather.txt
 (rocprofv3 -L 2>&1 || rocprofv3-avail list 2>&1) > $O/counters_all.txt; grep -o -E "\b(TCC|TCP|TA|TD|SQ|GRBM)_[A-Za-z0-9_]+" $O/counters_all.txt | sort -u > $O/counters.txt; wc -l $O/counters.txt
 B="env PIGO_SIDE_STREAM=0 python bench.py --frames 64 --steps 3 --warmup 1 --no-cpu-baseline --no-single-frame --no-gray --shard-frames 0 --verify-frames 0"

@@ -1,6 +1,7 @@
 # Round-3 diagnostics 2: cache-policy microbenchmark, kernel traces of the 4K config and the default config
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r3; mkdir -p $O
+[ -x scripts/micro/ta_policy ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/micro/ta_policy.hip -o scripts/micro/ta_policy
 timeout 120 scripts/micro/ta_policy 2000 > $O/ta_policy.txt 2>&1; echo "ta_policy rc=$?"; grep "waves/CU 16" $O/ta_policy.txt | cut -c1-150
 K4="python bench.py --rows 2160 --cols 3840 --min-size 20 --max-size 2000 --shift 0.05 --scale 1.05 --frames 8 --det-cap 32768 --gather-cap 64 --steps 3 --warmup 1 --no-cpu-baseline --no-gray --shard-frames 0 --verify-frames 0 --no-single-frame"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace4k -o t -- $K4 > $O/trace4k.log 2>&1; echo "trace4k rc=$?"
