@@ -735,15 +735,26 @@ bool build_region_groups(pigo_plan &p)
         }
         if (k == k_lo) continue;
         if (k - k_lo > kRegMaxScales) REG_BAIL;
-        const size_t fixed = (size_t)nh * 64 * 8 + (size_t)(kRegThreads / 64) * ((size_t)chunkg[g] * 6 + kRegWavePool * 8) + (size_t)deepg[g] * 8 +
-                             (size_t)(k - k_lo) * t_pool * 256;
+        // The deep list is sized for the windows a region holds: 1024 / 512 entries are right for the 1080p config's ~72 k / ~5.5 k
+        // windows per region, but a dense ladder (the 4K stress config: shift 0.05, scale 1.05 -- several hundred thousand windows
+        // per region) overflowed them into k_tail_deep's queue: 2 ms of a 15 ms step.  Pass 0 sizes the cells with the default,
+        // counts the region's windows and, if the list is short for them, pass 1 sizes again with a longer one (<= 2048 entries:
+        // the LDS it takes comes out of the cell).
+        int deep_cap_g = deepg[g];
+        const double deep_per_window[NG] = {0.0125, 0.026, 0.026};  // (the 1080p config: 81 k windows -> 1024, 6 k -> the 512 minimum)
+        const bool deep_fixed = getenv(g == 0 ? "PIGO_REG_DEEP0" : g == 1 ? "PIGO_REG_DEEP1" : "PIGO_REG_DEEP2") != nullptr;
+        size_t fixed = 0;
+        RegionArgs r{};
+        const int halo = up + dn;
+        for (int pass = 0; pass < 2 && !dropped; ++pass) {
+        fixed = (size_t)nh * 64 * 8 + (size_t)(kRegThreads / 64) * ((size_t)chunkg[g] * 6 + kRegWavePool * 8) + (size_t)deep_cap_g * 8 +
+                (size_t)(k - k_lo) * t_pool * 256;
         if (fixed + 16384 > max_dyn) REG_BAIL;
         const size_t budget = max_dyn - fixed;
-        const int halo = up + dn;
         // the largest cell whose region fits; then as many equal cells as the image needs; more, smaller cells when the
         // plan's batch is too small to give every CU a workgroup
         double shrink = 1.0;
-        RegionArgs r{};
+        r = RegionArgs{};
         for (;;) {
             int cw_max = std::max(32, (int)(cwmax[g] * shrink)) & ~3;
             int pitch_max = (cw_max + halo + 3 + 3) & ~3;
@@ -761,6 +772,19 @@ bool build_region_groups(pigo_plan &p)
             shrink *= 0.8;
         }
         if ((size_t)r.pitch * r.rows > budget) REG_BAIL;
+        if (pass == 0 && !deep_fixed) {
+            long long wins = 0;
+            for (int j = k_lo; j < k; ++j)
+                wins += (long long)((r.cell_h + p.scales[j].step - 1) / p.scales[j].step) * ((r.cell_w + p.scales[j].step - 1) / p.scales[j].step);
+            const int want = std::min(2048, (int)((wins * deep_per_window[g] + 255) / 256) * 256);
+            if (want > deep_cap_g) {
+                deep_cap_g = want;
+                continue;
+            }
+        }
+        break;
+        }
+        if (dropped) break;
         if ((long long)std::max(up, dn) * r.pitch + std::max(up, dn) > 32767) REG_BAIL;  // packed int16 offsets
         if ((size_t)r.pitch * r.rows + fixed + 2048 >= (1u << 18)) REG_BAIL;  // pool entries hold an 18-bit LDS address
         for (int j = k_lo; j < k; ++j) {  // queue entries hold a window's index within (rung, cell) in 16 bits
@@ -776,7 +800,7 @@ bool build_region_groups(pigo_plan &p)
         r.t_pool = t_pool;
         r.nh = nh;
         r.wave_chunk = chunkg[g];
-        r.deep_cap = deepg[g];
+        r.deep_cap = deep_cap_g;
         // the 64 x 65 dwords of the first deep pass's codes must fit the wave queues + pools (16.25 KiB)
         r.deep_lds_codes = (env_int("PIGO_REG_DEEP_LDS", 1) != 0 &&
                             (size_t)(kRegThreads / 64) * ((size_t)chunkg[g] * 6 + kRegWavePool * 8) >= (size_t)64 * 65 * 4) ? 1 : 0;
