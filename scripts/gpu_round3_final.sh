@@ -7,6 +7,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; cut -c1-500 $O/bench_default.json; tail -2 $O/bench_default.err
 timeout 300 python bench.py --kind noise --no-cpu-baseline --no-gray --shard-frames 0 > $O/bench_noise.json 2> $O/bench_noise.err; echo "noise rc=$?"; cut -c1-200 $O/bench_noise.json
 timeout 300 python bench.py --angle 0.8 --no-cpu-baseline --no-gray --shard-frames 0 > $O/bench_rot.json 2> $O/bench_rot.err; echo "rot rc=$?"; cut -c1-200 $O/bench_rot.json
+timeout 300 python bench.py --angle 0.8 --face-rotation -79 --no-cpu-baseline --no-gray --shard-frames 0 > $O/bench_rot_rotfaces.json 2> $O/bench_rot_rotfaces.err; echo "rot_rotfaces rc=$?"; cut -c1-200 $O/bench_rot_rotfaces.json
 timeout 300 python bench.py --rows 2160 --cols 3840 --min-size 20 --max-size 2000 --shift 0.05 --scale 1.05 --frames 8 --det-cap 32768 --gather-cap 64 --steps 5 --warmup 2 --no-cpu-baseline --no-gray --shard-frames 0 --verify-frames 2 > $O/bench_4k.json 2> $O/bench_4k.err; echo "4k rc=$?"; cut -c1-200 $O/bench_4k.json; tail -2 $O/bench_4k.err
 timeout 300 python bench.py --frames 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gray --shard-frames 0 --verify-frames 1 --no-single-frame > $O/bench_1frame.json 2> $O/bench_1frame.err; echo "1frame rc=$?"; cut -c1-300 $O/bench_1frame.json
 python scripts/single_frame_latency.py 2>&1 | grep "single 1080p" | tee $O/single_frame.txt
