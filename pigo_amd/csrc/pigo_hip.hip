@@ -191,6 +191,7 @@ struct pigo_plan {
     bool tab_global = false;             // LDS-pixel classes read their offset tables from global memory (L1) instead of LDS
     size_t deep_lds = 0, deep_lds2 = 0;  // dynamic LDS of the two k_tail_deep launches
     int deep_mid = 0;                    // first launch walks [deep_lo, deep_mid), second [deep_mid, ntrees)
+    int nh_reg_mid = 0;                  // variant 3: the mid scale group's hand-over tree (the small group's is nh_lds)
     DevBuf<QEntry> d_queue2;
     long long qcap2 = 0;
     DevBuf<QEntry> d_queue;
@@ -508,6 +509,10 @@ bool build_tile_stages(pigo_plan &p)
     const bool v3_plan = (!p.rot || p.rot_lds) && p.key.dim % 4 == 0 && p.max_frames >= 8;
     a.nh_glb = std::min(nt, std::max(1, (p.rot && !p.rot_lds) ? env_int("PIGO_NH_ROT", 18) : env_int("PIGO_NH_GLB", v3_plan ? 48 : 28)));
     a.deep_lo = std::min(a.nh_lds, a.nh_glb);
+    // (variant 3's mid scale group hands its survivors to the deep list earlier than the small group -- build_region_groups --
+    // and a deep list that overflows spills into k_tail_deep's queue: its code table has to start there)
+    p.nh_reg_mid = std::min(a.nh_lds, std::max(1, env_int("PIGO_NH_REG1", 13)));
+    if (v3_plan) a.deep_lo = std::min(a.deep_lo, p.nh_reg_mid);
     // LDS table capacity per class: enough for the trees the class walks before handing off; the dense stages'
     // table windows are planned for the smaller of the two so that they fit either
     p.tab_lds = std::min(kTabTrees, std::max(a.nh_lds, 8));
@@ -689,8 +694,19 @@ bool build_region_groups(pigo_plan &p)
     const ScanArgs &a = p.args;
     // (rotated scans: only where the clamp-free LDS form exists -- rot_lds: no Go panic possible, see k_scan_tile's loader)
     if (!p.tile_ok || (p.rot && !p.rot_lds) || p.key.dim % 4 != 0 || p.scales.empty()) return false;
-    const int nh = std::min(a.nh_lds, a.nh_glb);
-    if (nh < 1 || nh > kTabTrees || a.deep_lo != nh) return false;
+    const int nh0 = std::min(a.nh_lds, a.nh_glb);
+    if (nh0 < 1 || nh0 > kTabTrees || a.deep_lo > nh0) return false;
+    // The hand-over tree per group: 28 for the small group (it loses with less: 3.81 -> 3.94 ms at 18).  The mid group's survivors
+    // are mostly face windows that go a long way: lane = tree takes them over at tree 13 already and fifteen trees' leaves and
+    // codes less stay resident -- mid group 1.85 -> 1.55 ms at the 1080p config (18: 1.73, 9: 1.60, 6: 1.66).  Not where a
+    // region holds tens of thousands of mid-scale windows (the 4K stress config): there the earlier hand-over floods the deep
+    // list (64.2 -> 61.2 Gwindows/s even with longer lists), so the group loop below decides by the windows per region unless
+    // PIGO_NH_REG1 forces a tree.  It must sit right behind a stage end.
+    int nh1 = nh0;
+    for (int st = 0; st < a.n_stages; ++st)
+        if (a.st_end[st] + 1 == p.nh_reg_mid && p.nh_reg_mid >= a.deep_lo && p.nh_reg_mid <= nh0) nh1 = p.nh_reg_mid;
+    const bool nh1_forced = getenv("PIGO_NH_REG1") != nullptr;
+    int nh = nh0;
     // chunk stages: the leading stages that end below the pooling tree
     const int t_pool_wanted = std::max(1, env_int("PIGO_REG_POOL_TREE", 4));
     int n_cs = 0;
@@ -724,6 +740,7 @@ bool build_region_groups(pigo_plan &p)
     }
     bool dropped = false;
     for (int g = 0; g < NG && k < nscales && !dropped; ++g) {
+        nh = (g >= 1 && nh1_forced) ? nh1 : nh0;
         const int k_lo = k;
         int up = 0, dn = 0;
         while (k < nscales && p.scales[k].s <= smax[g]) {
@@ -772,15 +789,21 @@ bool build_region_groups(pigo_plan &p)
             shrink *= 0.8;
         }
         if ((size_t)r.pitch * r.rows > budget) REG_BAIL;
-        if (pass == 0 && !deep_fixed) {
+        if (pass == 0) {
             long long wins = 0;
             for (int j = k_lo; j < k; ++j)
                 wins += (long long)((r.cell_h + p.scales[j].step - 1) / p.scales[j].step) * ((r.cell_w + p.scales[j].step - 1) / p.scales[j].step);
-            const int want = std::min(2048, (int)((wins * deep_per_window[g] + 255) / 256) * 256);
-            if (want > deep_cap_g) {
-                deep_cap_g = want;
-                continue;
+            bool again = false;
+            if (g >= 1 && !nh1_forced && nh != nh1 && wins <= 16384) {  // few mid-scale windows per region: hand over early
+                nh = nh1;
+                again = true;
             }
+            const int want = std::min(2048, (int)((wins * deep_per_window[g] + 255) / 256) * 256);
+            if (!deep_fixed && want > deep_cap_g) {
+                deep_cap_g = want;
+                again = true;
+            }
+            if (again) continue;
         }
         break;
         }
