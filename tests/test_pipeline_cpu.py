@@ -119,3 +119,27 @@ def test_find_faces_on_the_oracle_engine():
     got = pipeline.find_faces(frame, engine=OracleEngine())
     assert got.dtype == np.int64 and got.ndim == 2 and got.shape[1] == 3 and len(got) >= 1
     assert (got[:, 2] >= 100).all() and (got[:, 2] <= 600).all()
+
+
+def test_bench_verification_covers_both_ends_of_a_batch():
+    """bench.py checks the first and the last frames of the timed batch against the oracle (the head of the XCD dealing and the
+    `nframes % 8` remainder / last pipeline chunk)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.verify_frame_indices(128, 8) == [0, 1, 2, 3, 124, 125, 126, 127]
+    assert bench.verify_frame_indices(13, 8) == [0, 1, 2, 3, 9, 10, 11, 12]
+    assert bench.verify_frame_indices(5, 8) == [0, 1, 2, 3, 4]
+    assert bench.verify_frame_indices(1, 8) == [0]
+    assert bench.verify_frame_indices(1024, 4) == [0, 1, 1022, 1023]
+
+
+def test_synthetic_frames_with_rotated_faces_are_seeded_and_differ_from_upright():
+    """synth.make_frames(rotate_deg=...) -- the frames bench.py --face-rotation scans: deterministic, and not the upright ones."""
+    from pigo_amd import synth
+    a = synth.make_frames("faces", 2, 240, 320, seed=3, rotate_deg=-79.0)
+    b = synth.make_frames("faces", 2, 240, 320, seed=3, rotate_deg=-79.0)
+    c = synth.make_frames("faces", 2, 240, 320, seed=3)
+    assert a.shape == (2, 240, 320) and a.dtype == c.dtype and (a == b).all() and not (a == c).all()
