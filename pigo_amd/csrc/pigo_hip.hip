@@ -720,11 +720,41 @@ bool build_region_groups(pigo_plan &p)
     // result, every threshold is still tested in order -- for one compaction and one dependent stage less (mid group
     // 1.56 -> 1.45 ms; the small group, eight windows per lane in stage 0, loses with it: 3.81 -> 3.91).
     const bool mid_merge = env_int("PIGO_REG_MERGE1", 1) != 0 && n_cs == 4 && cs_end[0] == 0 && cs_end[1] == 1 && cs_end[2] == 2 && cs_end[3] == 3;
-    const int n_cs_g[3] = {n_cs, mid_merge ? 2 : n_cs, mid_merge ? 2 : n_cs};
-    const int t_pool_g[3] = {t_pool, mid_merge ? 3 : t_pool, mid_merge ? 3 : t_pool};
-    const int cs_end_g[3][4] = {{cs_end[0], cs_end[1], cs_end[2], cs_end[3]},
-                                {mid_merge ? 0 : cs_end[0], mid_merge ? 2 : cs_end[1], mid_merge ? 0 : cs_end[2], mid_merge ? 0 : cs_end[3]},
-                                {mid_merge ? 0 : cs_end[0], mid_merge ? 2 : cs_end[1], mid_merge ? 0 : cs_end[2], mid_merge ? 0 : cs_end[3]}};
+    // The small group merges the OTHER pair: [0] [1] [2-3], pool from tree 4 as before (3.82 -> 3.75 ms; [0] [1-2] loses there,
+    // [0] [1-3] and a fifth stage lose badly: profiles/r03_experiments.md section 19).
+    const bool small_merge = env_int("PIGO_REG_MERGE0", 1) != 0 && n_cs == 4 && cs_end[0] == 0 && cs_end[1] == 1 && cs_end[2] == 2 && cs_end[3] == 3;
+    int n_cs_g[3] = {small_merge ? 3 : n_cs, mid_merge ? 2 : n_cs, mid_merge ? 2 : n_cs};
+    int t_pool_g[3] = {t_pool, mid_merge ? 3 : t_pool, mid_merge ? 3 : t_pool};
+    int cs_end_g[3][4] = {{cs_end[0], cs_end[1], small_merge ? 3 : cs_end[2], small_merge ? 0 : cs_end[3]},
+                          {mid_merge ? 0 : cs_end[0], mid_merge ? 2 : cs_end[1], mid_merge ? 0 : cs_end[2], mid_merge ? 0 : cs_end[3]},
+                          {mid_merge ? 0 : cs_end[0], mid_merge ? 2 : cs_end[1], mid_merge ? 0 : cs_end[2], mid_merge ? 0 : cs_end[3]}};
+    // (experiments: PIGO_REG_CS0 / PIGO_REG_CS1 = "e0,e1,..": the last tree of every chunk stage of the small / mid group; every
+    // end must be a stage end of the cascade, at most four, ascending, below the hand-over tree)
+    for (int g = 0; g < 2; ++g) {
+        const char *e = getenv(g == 0 ? "PIGO_REG_CS0" : "PIGO_REG_CS1");
+        if (!e || !*e) continue;
+        int v[4], nv = 0;
+        for (const char *q = e; *q && nv < 4;) {
+            v[nv++] = atoi(q);
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+        bool ok = nv >= 1;
+        for (int i = 0; i < nv && ok; ++i) {
+            bool is_end = false;
+            for (int st = 0; st < a.n_stages; ++st) is_end = is_end || a.st_end[st] == v[i];
+            ok = is_end && (i == 0 || v[i] > v[i - 1]) && v[i] + 1 < nh0 && v[i] + 1 <= kTabTrees;
+        }
+        if (!ok) continue;
+        n_cs_g[g] = nv;
+        t_pool_g[g] = v[nv - 1] + 1;
+        for (int i = 0; i < 4; ++i) cs_end_g[g][i] = i < nv ? v[i] : 0;
+        if (g == 1) {
+            n_cs_g[2] = n_cs_g[1];
+            t_pool_g[2] = t_pool_g[1];
+            for (int i = 0; i < 4; ++i) cs_end_g[2][i] = cs_end_g[1][i];
+        }
+    }
     const int pool_cap = kRegWavePool;
     // leaves + raw codes of the nh trees, per wave a queue of kRegWaveChunk 6-byte and a pool of kRegWavePool 8-byte entries;
     // plus, per group, the offset tables of the chunk-stage trees of every scale of the group
