@@ -585,6 +585,9 @@ def main():
                                   "the stream, as rocprofv3 sees them); the timed step overlaps them, so ms_per_step can be below their sum",
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items() if k != "end"},
             "cluster_ms": round(cluster_ms, 4) if cluster_ms is not None else None,
+            # what running the big scales' launches NEXT to the region launches hides: (sum of the per-kernel times, each launch alone
+            # on the stream) + the cluster step - the timed step
+            "overlap_ms": round(sum(v for k, v in ktimes.items() if k != "end") + (cluster_ms or 0.0) - elapsed / args.steps * 1e3, 4),
             "roofline": {
                 "bound": "hbm", "kernel": "k_" + dom, "kernel_ms_per_batch": round(scan_ms, 4),
                 "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

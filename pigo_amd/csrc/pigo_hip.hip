@@ -175,6 +175,15 @@ struct pigo_plan {
     };
     std::vector<RegionGroup> regions;
     bool region_ok = false;
+    // variant 3, the rungs beyond the region groups: k_scan_big (persistent, one small workgroup per CU NEXT to a region
+    // workgroup) + a chain of k_tail_deep launches whose code windows fit the LDS the region groups leave free
+    bool big_ok = false;
+    BigArgs big{};
+    DevBuf<uint2> d_big_items;
+    std::vector<uint2> big_items;
+    size_t big_lds = 0;
+    size_t side_lds = 0;                 // LDS a region workgroup of group 0 leaves to a co-resident side workgroup (0: none reserved)
+    std::vector<int> side_splits;        // code windows of the side chain's k_tail_deep launches: [splits[i], splits[i+1])
     bool tile_patch = true;              // variant 3: do the tile classes' survivors include scales <= kPatchMaxS?
     DevBuf<uint32_t> d_tabr;
     // variant 3, rungs beyond the region groups: survivors binned by position for k_tail_patch
@@ -765,7 +774,15 @@ bool build_region_groups(pigo_plan &p)
     // (deep lists of 1024 / 512 entries: 768 / 1024 / 1536 for the small group measure 65.3 / 65.5 / 64.7 k -- the LDS goes to
     // the cell instead --, 256 for the mid group starts to spill on the benchmark frames)
     const int deepg[NG] = {std::max(64, env_int("PIGO_REG_DEEP0", 1024)), std::max(64, env_int("PIGO_REG_DEEP1", 512)), std::max(64, env_int("PIGO_REG_DEEP2", 256))};
-    const size_t max_dyn = (size_t)(160 << 10) - 3072;  // static LDS of k_scan_region: per-scale geometry, counters, thresholds
+    // static LDS of k_scan_region (per-scale geometry, counters, thresholds): 3072.  Plans that have rungs beyond the groups give
+    // the big scales' kernels (k_scan_big, k_tail_deep: bound by the vector-memory path the region kernel leaves idle) room for
+    // one small workgroup on the same CU: the first group -- the launch they run next to -- takes that much less (PIGO_REG_RESERVE0_KB,
+    // PIGO_REG_RESERVE1_KB for the second group; 0 = the whole CU).
+    const bool has_big = p.scales.back().s > env_int("PIGO_REG_S1", 148) && env_int("PIGO_BIG", 1) != 0;
+    const size_t reserve_g[3] = {(size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE0_KB", has_big ? 36 : 0))) << 10,
+                                 (size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE1_KB", 0))) << 10, 0};
+    p.side_lds = reserve_g[0];
+    const size_t max_dyn_all = (size_t)(160 << 10) - 3072;
     // (group limits: 51 / 148 measured best after the deep list got cheaper -- 42…51 / 148 within 0.3 %, 62 / 135 3 % slower)
     const int smax[NG] = {env_int("PIGO_REG_S0", 51), env_int("PIGO_REG_S1", 148), 0};
     const int cwmax[NG] = {env_int("PIGO_REG_CW0", 320), env_int("PIGO_REG_CW1", 192), env_int("PIGO_REG_CW2", 128)};
@@ -801,6 +818,7 @@ bool build_region_groups(pigo_plan &p)
         // per region) overflowed them into k_tail_deep's queue: 2 ms of a 15 ms step.  Pass 0 sizes the cells with the default,
         // counts the region's windows and, if the list is short for them, pass 1 sizes again with a longer one (<= 2048 entries:
         // the LDS it takes comes out of the cell).
+        const size_t max_dyn = max_dyn_all - reserve_g[g];
         int deep_cap_g = deepg[g];
         const double deep_per_window[NG] = {0.0125, 0.026, 0.026};  // (the 1080p config: 81 k windows -> 1024, 6 k -> the 512 minimum)
         const bool deep_fixed = getenv(g == 0 ? "PIGO_REG_DEEP0" : g == 1 ? "PIGO_REG_DEEP1" : "PIGO_REG_DEEP2") != nullptr;
@@ -889,6 +907,66 @@ bool build_region_groups(pigo_plan &p)
     p.tile_patch = kbig < nscales && p.scales[kbig].s <= kPatchMaxS;
 
     return true;
+}
+
+// Variant 3: the rungs beyond the last region group go through k_scan_big (+ a chain of k_tail_deep launches that fits the LDS
+// the first region group leaves free).  Cuts those rungs' windows into chunks of kBigChunk and plans the stages.
+pigo_status build_big(pigo_plan &p)
+{
+    p.big_ok = false;
+    p.big_items.clear();
+    p.side_splits.clear();
+    const ScanArgs &a = p.args;
+    const pigo_cascade &c = *p.c;
+    const int nt = (int)c.ntrees, nscales = (int)p.scales.size();
+    if (!p.region_ok || p.regions.empty() || env_int("PIGO_BIG", 1) == 0) return PIGO_OK;
+    const int kbig = p.regions.back().args.k_hi;
+    if (kbig >= nscales) return PIGO_OK;
+    // hand-over tree: right behind a stage end, as for the tile classes (48 for the facefinder: the next real threshold after 27)
+    int nh = std::min(a.nh_glb, std::min(nt, kTabTrees));
+    {
+        bool at_end = nh == nt;
+        for (int st = 0; st < a.n_stages; ++st) at_end = at_end || a.st_end[st] + 1 == nh;
+        if (!at_end) return PIGO_OK;
+    }
+    BigArgs &B = p.big;
+    B = BigArgs{};
+    // chunk stages: [0] [1] [2-3] where the cascade's first stages are single trees (as the small region group), else its own first stages
+    int n_cs = 0;
+    while (n_cs < a.n_stages && n_cs < 4 && a.st_end[n_cs] < std::max(1, env_int("PIGO_BIG_POOL_TREE", 4)) && a.st_end[n_cs] + 1 < nh) ++n_cs;
+    if (n_cs < 1) return PIGO_OK;
+    for (int i = 0; i < n_cs; ++i) B.cs_end[i] = a.st_end[i];
+    if (env_int("PIGO_BIG_MERGE", 1) != 0 && n_cs == 4 && B.cs_end[0] == 0 && B.cs_end[1] == 1 && B.cs_end[2] == 2 && B.cs_end[3] == 3) {
+        B.cs_end[2] = 3;
+        B.cs_end[3] = 0;
+        n_cs = 3;
+    }
+    B.n_cs = n_cs;
+    B.t_pool = B.cs_end[n_cs - 1] + 1;
+    B.nh = nh;
+    for (int k = kbig; k < nscales; ++k) {
+        const ScaleDesc &sd = p.scales[k];
+        if (sd.s >= 65536 || sd.nc >= 65536 - kBigChunk) return PIGO_OK;  // (big_decode's 24-bit arithmetic; plan_build limits rows/cols to 65535 anyway)
+        const long long nwin = (long long)sd.nr * sd.nc;
+        for (long long f0 = 0; f0 < nwin; f0 += kBigChunk) p.big_items.push_back(make_uint2((unsigned)k, (unsigned)f0));
+    }
+    if (p.big_items.empty() || p.big_items.size() > (1u << 24)) return PIGO_OK;
+    B.cpf = (uint32_t)p.big_items.size();
+    p.big_lds = (size_t)nh * 256 + (size_t)kBigWaves * (kBigChunk * 6 + kBigPool * 16);
+    // the side chain's k_tail_deep launches: code windows of at most as many trees as fit the reserved LDS (one allocation granule
+    // of slack), at least 64 (one pass); without a reserve the two classic windows
+    if (nh < nt) {
+        const size_t cap_bytes = p.side_lds > 2048 ? p.side_lds - 1536 : (size_t)(160 << 10) - 1024;
+        int wmax = (int)std::min<size_t>(cap_bytes / ((size_t)kCodeStride * 4), (size_t)std::max(64, env_int("PIGO_BIG_DEEP_SPLIT", p.side_lds ? 128 : 192)));
+        wmax = std::max(wmax, 64);
+        if ((size_t)wmax * kCodeStride * 4 > (size_t)(160 << 10) - 1024) return PIGO_OK;
+        for (int t = nh; t < nt; t += wmax) p.side_splits.push_back(t);
+        p.side_splits.push_back(nt);
+        if (p.side_splits.size() > 7) return PIGO_OK;  // (counters 8..15 of a queue set)
+    }
+    if (p.side_lds && p.big_lds + 1536 > p.side_lds) p.side_lds = 0;  // does not fit the reserve: runs, but not next to a region workgroup
+    p.big_ok = true;
+    return PIGO_OK;
 }
 
 int env_int(const char *name, int dflt)
@@ -1046,6 +1124,16 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
             HIP_TRY(hipStreamSynchronize(bs.s));  // (before sreg / d_sreg go out of scope)
             HIP_TRY(hipFuncSetAttribute((const void *)k_scan_region<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 3072));
             HIP_TRY(hipFuncSetAttribute((const void *)k_scan_region<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 3072));
+            st = build_big(*p);
+            if (st != PIGO_OK) return st;
+            if (p->big_ok) {
+                HIP_TRY(p->d_big_items.alloc(p->big_items.size()));
+                HIP_TRY(hipMemcpyAsync(p->d_big_items.p, p->big_items.data(), p->big_items.size() * sizeof(uint2), hipMemcpyHostToDevice, bs.s));
+                HIP_TRY(hipStreamSynchronize(bs.s));
+                p->big.items = p->d_big_items.p;
+                HIP_TRY(hipFuncSetAttribute((const void *)k_scan_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->big_lds));
+                HIP_TRY(hipFuncSetAttribute((const void *)k_scan_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->big_lds));
+            }
         }
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
@@ -1293,6 +1381,51 @@ void launch_tail(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry
     }
 }
 
+// variant 3, the rungs beyond the region groups: k_scan_big fills the 8 per-XCD queues of `a`, then one k_tail_deep launch per
+// code window of p.side_splits drains them -- each hands what is still alive to the next through the two halves of `queue2`
+// (counters a.qcount[8 + i]).  With an LDS reserve in the region groups (p.side_lds) every launch is ONE workgroup of 8 waves
+// per CU, <= 64 VGPRs and <= p.side_lds of LDS: it fits next to a resident k_scan_region workgroup (16 waves x 96 VGPRs).
+template <bool ROT, bool GUARD, class Mark>
+void launch_big(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry *queue2, uint32_t cap2, hipStream_t s, Mark &mark)
+{
+    ScanArgs ba = a;
+    ba.qcap = xcd_cap;
+    ba.big = p.big;
+    ba.big.next = a.qcount + 40;
+    const int per_cu = std::max(1, env_int("PIGO_BIG_PER_CU", 1));
+    mark("scan_big");
+    k_scan_big<ROT><<<256 * per_cu, kBigThreads, p.big_lds, s>>>(ba);
+    static const char *names[] = {"tail_deep", "tail_deep2", "tail_deep3", "tail_deep4", "tail_deep5", "tail_deep6"};
+    const int nl = (int)p.side_splits.size() - 1;
+    const uint32_t capq = cap2 / 2;
+    const int threads = p.side_lds ? 512 : kDeepThreads;
+    const int tail_per_cu = std::max(1, env_int("PIGO_BIG_TAIL_PER_CU", 1));
+    for (int i = 0; i < nl; ++i) {
+        ScanArgs ta = a;
+        ta.deep_lo = p.side_splits[i];
+        ta.deep_hi = p.side_splits[i + 1];
+        if (i == 0) {
+            ta.qcap = xcd_cap;
+            ta.nqueues = 8;
+        } else {
+            ta.queue = queue2 + (size_t)((i - 1) & 1) * capq;
+            ta.qcount = a.qcount + 8 + (i - 1);
+            ta.qcap = capq;
+            ta.nqueues = 1;
+        }
+        const bool last = i == nl - 1;
+        ta.queue2 = last ? nullptr : queue2 + (size_t)(i & 1) * capq;
+        ta.qcount2 = last ? nullptr : a.qcount + 8 + i;
+        ta.qcap2 = last ? 0 : capq;
+        const size_t lds = (size_t)(ta.deep_hi - ta.deep_lo) * kCodeStride * 4;
+        mark(names[std::min(i, 5)]);
+        if constexpr (ROT)
+            k_tail_deep<true, GUARD, false><<<256 * tail_per_cu, threads, lds, s>>>(ta);
+        else
+            k_tail_deep<false, false, false><<<256 * tail_per_cu, threads, lds, s>>>(ta);
+    }
+}
+
 template <bool ROT, bool GUARD, class Mark>
 void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t s, Mark &mark)
 {
@@ -1335,7 +1468,9 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
                     patched = true;
                 }
             }
-            if (!patched) {
+            if (!patched && p.big_ok) {
+                launch_big<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, sa, mark);
+            } else if (!patched) {
                 launch_tiles<ROT, GUARD>(p, aa, xcd_cap, sa, mark, true, 2);
                 launch_tail<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, sa, mark, p.tile_patch);
             }
