@@ -99,6 +99,7 @@ struct pigo_cascade {
     DevBuf<int8_t> d_codes;
     DevBuf<float> d_leaf, d_thr;
     DevBuf<int16_t> d_pass_end;          // k_tail_deep: the lane=tree pass that starts at tree t covers trees [t, d_pass_end[t])
+    DevBuf<uint2> d_codes_t;             // depth-6 cascades: child-pair table, node-major [32][ntrees] (pigo_cascade_create)
     std::mutex mu;                       // guards the slot list below and pigo_cluster_detections' scratch
     // RunCascade slots: everything one call needs (plan, device + pinned host buffers, a stream, the captured graph of
     // "upload, scan, download").  A call takes a free slot with its parameters (or makes one), so goroutines calling RunCascade on
@@ -183,6 +184,7 @@ struct pigo_plan {
     std::vector<uint2> big_items;
     size_t big_lds = 0;
     size_t side_lds = 0;                 // LDS a region workgroup of group 0 leaves to a co-resident side workgroup (0: none reserved)
+    bool big_ct = false;                 // the side chain's k_tail_deep reads its codes from global memory (no LDS table)
     std::vector<int> side_splits;        // code windows of the side chain's k_tail_deep launches: [splits[i], splits[i+1])
     bool tile_patch = true;              // variant 3: do the tile classes' survivors include scales <= kPatchMaxS?
     DevBuf<uint32_t> d_tabr;
@@ -366,6 +368,20 @@ extern "C" pigo_status pigo_cascade_create(const uint8_t *packet, size_t len, in
         }
         HIP_TRY(c->d_pass_end.alloc(pe.size()));
         HIP_TRY(hipMemcpy(c->d_pass_end.p, pe.data(), pe.size() * 2, hipMemcpyHostToDevice));
+        if (depth == 6) {
+            // Child-pair table, node-major: codes_t[p * ntrees + t] = the code words of nodes 2p and 2p+1 of tree t (p = 0: {unused,
+            // root}).  Where every lane walks its OWN tree (k_tail_deep: lane = tree; k_scan_big's pool) a level's fetch touches the
+            // rows of the nodes the lanes stand on -- 2^level of them, each 8 bytes per tree apart -- instead of one 256-byte tree
+            // per lane: a third of the cache lines, which is what lets those kernels read the codes from global memory and run
+            // without an LDS code table next to a k_scan_region workgroup.
+            std::vector<uint32_t> ct((size_t)32 * ntrees * 2);
+            for (uint32_t t = 0; t < ntrees; ++t)
+                for (int pp = 0; pp < 32; ++pp) {
+                    memcpy(&ct[((size_t)pp * ntrees + t) * 2], c->codes.data() + ((size_t)t * 64 + 2 * pp) * 4, 8);
+                }
+            HIP_TRY(c->d_codes_t.alloc(ct.size() / 2));
+            HIP_TRY(hipMemcpy(c->d_codes_t.p, ct.data(), ct.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     *out = c.release();
     return PIGO_OK;
@@ -779,7 +795,7 @@ bool build_region_groups(pigo_plan &p)
     // one small workgroup on the same CU: the first group -- the launch they run next to -- takes that much less (PIGO_REG_RESERVE0_KB,
     // PIGO_REG_RESERVE1_KB for the second group; 0 = the whole CU).
     const bool has_big = p.scales.back().s > env_int("PIGO_REG_S1", 148) && env_int("PIGO_BIG", 1) != 0;
-    const size_t reserve_g[3] = {(size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE0_KB", has_big ? 36 : 0))) << 10,
+    const size_t reserve_g[3] = {(size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE0_KB", has_big ? 16 : 0))) << 10,
                                  (size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE1_KB", 0))) << 10, 0};
     p.side_lds = reserve_g[0];
     const size_t max_dyn_all = (size_t)(160 << 10) - 3072;
@@ -825,8 +841,13 @@ bool build_region_groups(pigo_plan &p)
         size_t fixed = 0;
         RegionArgs r{};
         const int halo = up + dn;
+        // wave queues: with stage 0 = tree 0 alone its survivors go to a 2-byte queue (window index within the chunk | leaf index),
+        // and the {index, sum} queue behind it only holds wq entries at a time (reg_wave_batch): 28 instead of 48 KiB for 512-window chunks
+        const bool compress = env_int("PIGO_REG_COMPRESS", 1) != 0 && cs_end_g[g][0] == 0 && chunkg[g] <= 512;
+        const int wq = compress ? std::min(chunkg[g], std::max(64, env_int("PIGO_REG_WQ", 128) & ~63)) : chunkg[g];
+        const size_t wave_bytes = (compress ? (size_t)chunkg[g] * 2 : 0) + (size_t)wq * 6 + kRegWavePool * 8;
         for (int pass = 0; pass < 2 && !dropped; ++pass) {
-        fixed = (size_t)nh * 64 * 8 + (size_t)(kRegThreads / 64) * ((size_t)chunkg[g] * 6 + kRegWavePool * 8) + (size_t)deep_cap_g * 8 +
+        fixed = (size_t)nh * 64 * 8 + (size_t)(kRegThreads / 64) * wave_bytes + (size_t)deep_cap_g * 8 +
                 (size_t)(k - k_lo) * t_pool * 256;
         if (fixed + 16384 > max_dyn) REG_BAIL;
         const size_t budget = max_dyn - fixed;
@@ -836,17 +857,32 @@ bool build_region_groups(pigo_plan &p)
         r = RegionArgs{};
         for (;;) {
             int cw_max = std::max(32, (int)(cwmax[g] * shrink)) & ~3;
-            int pitch_max = (cw_max + halo + 3 + 3) & ~3;
-            if ((pitch_max / 4) % 2 == 0) pitch_max += 4;
-            int ch_max = (int)(budget / (size_t)pitch_max) - halo;
-            ch_max = std::max(16, (int)(ch_max * shrink));
-            r.ncx = (p.key.cols + cw_max - 1) / cw_max;
-            r.cell_w = (((p.key.cols + r.ncx - 1) / r.ncx) + 3) & ~3;
-            r.ncy = (p.key.rows + ch_max - 1) / ch_max;
-            r.cell_h = (p.key.rows + r.ncy - 1) / r.ncy;
-            r.pitch = (r.cell_w + halo + 3 + 3) & ~3;
-            if ((r.pitch / 4) % 2 == 0) r.pitch += 4;  // odd dword pitch: consecutive rows start on different banks
-            r.rows = r.cell_h + halo;
+            // the widest cells first, then up to six more columns of cells: the grid with the fewest regions wins (ties: the
+            // smaller region), so a budget that does not divide well by the widest cell is not wasted on a thin one
+            const int ncx0 = (p.key.cols + cw_max - 1) / cw_max;
+            long long best_n = -1, best_bytes = 0;
+            for (int ncx = ncx0; ncx <= ncx0 + (env_int("PIGO_REG_CELL_SEARCH", 1) != 0 ? 6 : 0); ++ncx) {
+                const int cell_w = (((p.key.cols + ncx - 1) / ncx) + 3) & ~3;
+                int pitch = (cell_w + halo + 3 + 3) & ~3;
+                if ((pitch / 4) % 2 == 0) pitch += 4;  // odd dword pitch: consecutive rows start on different banks
+                int ch_max = (int)(budget / (size_t)pitch) - halo;
+                if (ch_max < 16 && ncx > ncx0) continue;
+                ch_max = std::max(16, (int)(ch_max * shrink));
+                const int ncy = (p.key.rows + ch_max - 1) / ch_max;
+                const int cell_h = (p.key.rows + ncy - 1) / ncy;
+                const long long nreg = (long long)ncx * ncy, bytes = (long long)pitch * (cell_h + halo);
+                if (best_n < 0 || nreg < best_n || (nreg == best_n && bytes < best_bytes)) {
+                    best_n = nreg;
+                    best_bytes = bytes;
+                    r.ncx = ncx;
+                    r.cell_w = cell_w;
+                    r.ncy = ncy;
+                    r.cell_h = cell_h;
+                    r.pitch = pitch;
+                    r.rows = cell_h + halo;
+                }
+            }
+            const int ch_max = r.cell_h;
             if ((long long)r.ncx * r.ncy * p.max_frames >= env_int("PIGO_REG_MIN_REGIONS", 256) || (cw_max <= 32 && ch_max <= 16) || shrink < 0.05) break;
             shrink *= 0.8;
         }
@@ -888,8 +924,9 @@ bool build_region_groups(pigo_plan &p)
         r.wave_chunk = chunkg[g];
         r.deep_cap = deep_cap_g;
         // the 64 x 65 dwords of the first deep pass's codes must fit the wave queues + pools (16.25 KiB)
-        r.deep_lds_codes = (env_int("PIGO_REG_DEEP_LDS", 1) != 0 &&
-                            (size_t)(kRegThreads / 64) * ((size_t)chunkg[g] * 6 + kRegWavePool * 8) >= (size_t)64 * 65 * 4) ? 1 : 0;
+        r.deep_lds_codes = (env_int("PIGO_REG_DEEP_LDS", 1) != 0 && (size_t)(kRegThreads / 64) * wave_bytes >= (size_t)64 * 65 * 4) ? 1 : 0;
+        r.compress = compress ? 1 : 0;
+        r.wave_q = wq;
         for (int j = k_lo; j < k; ++j)
             if (p.scales[j].s >= (1 << 14)) REG_BAIL;
         if (dropped) break;
@@ -952,18 +989,17 @@ pigo_status build_big(pigo_plan &p)
     }
     if (p.big_items.empty() || p.big_items.size() > (1u << 24)) return PIGO_OK;
     B.cpf = (uint32_t)p.big_items.size();
-    p.big_lds = (size_t)nh * 256 + (size_t)kBigWaves * (kBigChunk * 6 + kBigPool * 16);
-    // the side chain's k_tail_deep launches: code windows of at most as many trees as fit the reserved LDS (one allocation granule
-    // of slack), at least 64 (one pass); without a reserve the two classic windows
+    p.big_lds = (size_t)kBigWaves * (kBigChunk * 6 + kBigPool * 16);
+    // the tail of the side chain: ONE k_tail_deep launch without an LDS code table (CT: codes from the node-major pair table in
+    // global memory) over all the remaining trees; PIGO_BIG_CT=0: launches with LDS code windows of PIGO_BIG_DEEP_SPLIT trees
+    p.big_ct = env_int("PIGO_BIG_CT", 1) != 0 && c.d_codes_t.p != nullptr;
     if (nh < nt) {
-        const size_t cap_bytes = p.side_lds > 2048 ? p.side_lds - 1536 : (size_t)(160 << 10) - 1024;
-        int wmax = (int)std::min<size_t>(cap_bytes / ((size_t)kCodeStride * 4), (size_t)std::max(64, env_int("PIGO_BIG_DEEP_SPLIT", p.side_lds ? 128 : 192)));
-        wmax = std::max(wmax, 64);
-        if ((size_t)wmax * kCodeStride * 4 > (size_t)(160 << 10) - 1024) return PIGO_OK;
+        const int wmax = p.big_ct ? nt : std::max(64, std::min(600, env_int("PIGO_BIG_DEEP_SPLIT", 192)));
         for (int t = nh; t < nt; t += wmax) p.side_splits.push_back(t);
         p.side_splits.push_back(nt);
         if (p.side_splits.size() > 7) return PIGO_OK;  // (counters 8..15 of a queue set)
     }
+    if (!p.big_ct) p.side_lds = 0;  // (LDS code windows do not fit next to a region workgroup)
     if (p.side_lds && p.big_lds + 1536 > p.side_lds) p.side_lds = 0;  // does not fit the reserve: runs, but not next to a region workgroup
     p.big_ok = true;
     return PIGO_OK;
@@ -1179,6 +1215,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.tabp = p->d_tabp.p;
     a.tabr = p->d_tabr.p;
     a.codes = c->d_codes.p;
+    a.codes_t = c->d_codes_t.p;
     a.pass_end = c->d_pass_end.p + (env_int("PIGO_DEEP_PASS", p->max_frames >= 8 ? 1 : 0) != 0 ? 0 : (size_t)c->ntrees);
     a.late_waves = std::max(1, std::min(kLateWaves, env_int("PIGO_LATE_WAVES", kLateWaves)));
     a.qb_div = 2;  // per class, see build_tile_classes
@@ -1417,12 +1454,15 @@ void launch_big(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry 
         ta.queue2 = last ? nullptr : queue2 + (size_t)(i & 1) * capq;
         ta.qcount2 = last ? nullptr : a.qcount + 8 + i;
         ta.qcap2 = last ? 0 : capq;
-        const size_t lds = (size_t)(ta.deep_hi - ta.deep_lo) * kCodeStride * 4;
+        const size_t lds = p.big_ct ? 0 : (size_t)(ta.deep_hi - ta.deep_lo) * kCodeStride * 4;
         mark(names[std::min(i, 5)]);
-        if constexpr (ROT)
-            k_tail_deep<true, GUARD, false><<<256 * tail_per_cu, threads, lds, s>>>(ta);
-        else
-            k_tail_deep<false, false, false><<<256 * tail_per_cu, threads, lds, s>>>(ta);
+        if constexpr (ROT) {
+            if (p.big_ct) k_tail_deep<true, GUARD, false, true><<<256 * tail_per_cu, threads, lds, s>>>(ta);
+            else k_tail_deep<true, GUARD, false><<<256 * tail_per_cu, threads, lds, s>>>(ta);
+        } else {
+            if (p.big_ct) k_tail_deep<false, false, false, true><<<256 * tail_per_cu, threads, lds, s>>>(ta);
+            else k_tail_deep<false, false, false><<<256 * tail_per_cu, threads, lds, s>>>(ta);
+        }
     }
 }
 
@@ -1453,6 +1493,11 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             aa.qcount = p.d_qcount.p;
             ab.queue = p.d_queue.p + half;
             ab.qcount = p.d_qcount.p + 16;
+            // which launch goes to the hardware first: with the region workgroups resident everywhere (one per CU, the reserve free)
+            // a side kernel's 256 workgroups land one per CU; launched into an empty chip the dispatcher may stack them
+            static const bool region_first = env_int("PIGO_BIG_FIRST", 0) == 0;
+            const bool reg_early = region_first && p.big_ok && !p.patch_ok;
+            if (reg_early) launch_tiles<ROT, GUARD>(p, ab, xcd_cap, s, mark, true, 1);
             bool patched = false;
             if constexpr (!ROT) {
                 if (p.patch_ok) {
@@ -1475,7 +1520,7 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
                 launch_tail<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, sa, mark, p.tile_patch);
             }
             if (fork) (void)hipEventRecord(p.ev_join, p.side);
-            launch_tiles<ROT, GUARD>(p, ab, xcd_cap, s, mark, true, 1);
+            if (!reg_early) launch_tiles<ROT, GUARD>(p, ab, xcd_cap, s, mark, true, 1);
             launch_tail<ROT, GUARD>(p, ab, xcd_cap, p.d_queue2.p + half2, (uint32_t)half2, s, mark);
             if (fork) (void)hipStreamWaitEvent(s, p.ev_join, 0);
         } else if (chunks <= 1) {
