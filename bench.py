@@ -63,6 +63,7 @@ def parse_args():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gray", action="store_true", help="skip the side measurements (RgbToGrayscale, RunDetector, single frame)")
+    ap.add_argument("--no-kernel-times", action="store_true", help="skip the per-kernel HIP-event pass (a rocprofv3 trace of the run then only holds overlapped steps)")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call leg (keeps kernel profiles per-batch)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto, ~15 s)")
     ap.add_argument("--face-rotation", type=float, default=0.0, help="rotate the pasted face patches by this many degrees (-79: what a scan at --angle 0.8 detects)")
@@ -364,7 +365,7 @@ def main():
     plan.set_profiling(True)
     ktimes = {}
     reps = 5
-    for _ in range(reps):
+    for _ in range(0 if args.no_kernel_times else reps):
         plan.run(d_frames, dets, counts)
         torch.cuda.synchronize()
         for name, ms in plan.last_timings():
