@@ -925,6 +925,7 @@ bool build_region_groups(pigo_plan &p)
         r.deep_cap = deep_cap_g;
         // the 64 x 65 dwords of the first deep pass's codes must fit the wave queues + pools (16.25 KiB)
         r.deep_lds_codes = (env_int("PIGO_REG_DEEP_LDS", 1) != 0 && (size_t)(kRegThreads / 64) * wave_bytes >= (size_t)64 * 65 * 4) ? 1 : 0;
+        r.prio = std::max(0, std::min(3, env_int("PIGO_REG_PRIO", 1)));
         r.compress = compress ? 1 : 0;
         r.wave_q = wq;
         for (int j = k_lo; j < k; ++j)
@@ -1430,8 +1431,9 @@ void launch_big(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry 
     ba.big = p.big;
     ba.big.next = a.qcount + 40;
     const int per_cu = std::max(1, env_int("PIGO_BIG_PER_CU", 1));
+    static const int skip = env_int("PIGO_BIG_SKIP", 0);  // timing experiments only (results incomplete): 1 = no tail, 2 = no k_scan_big
     mark("scan_big");
-    k_scan_big<ROT><<<256 * per_cu, kBigThreads, p.big_lds, s>>>(ba);
+    if (!(skip & 2)) k_scan_big<ROT><<<256 * per_cu, kBigThreads, p.big_lds, s>>>(ba);
     static const char *names[] = {"tail_deep", "tail_deep2", "tail_deep3", "tail_deep4", "tail_deep5", "tail_deep6"};
     const int nl = (int)p.side_splits.size() - 1;
     const uint32_t capq = cap2 / 2;
@@ -1456,6 +1458,7 @@ void launch_big(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry 
         ta.qcap2 = last ? 0 : capq;
         const size_t lds = p.big_ct ? 0 : (size_t)(ta.deep_hi - ta.deep_lo) * kCodeStride * 4;
         mark(names[std::min(i, 5)]);
+        if (skip & 1) continue;
         if constexpr (ROT) {
             if (p.big_ct) k_tail_deep<true, GUARD, false, true><<<256 * tail_per_cu, threads, lds, s>>>(ta);
             else k_tail_deep<true, GUARD, false><<<256 * tail_per_cu, threads, lds, s>>>(ta);
