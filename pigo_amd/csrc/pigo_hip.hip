@@ -844,7 +844,7 @@ bool build_region_groups(pigo_plan &p)
         // wave queues: with stage 0 = tree 0 alone its survivors go to a 2-byte queue (window index within the chunk | leaf index),
         // and the {index, sum} queue behind it only holds wq entries at a time (reg_wave_batch): 28 instead of 48 KiB for 512-window chunks
         const bool compress = env_int("PIGO_REG_COMPRESS", 1) != 0 && cs_end_g[g][0] == 0 && chunkg[g] <= 512;
-        const int wq = compress ? std::min(chunkg[g], std::max(64, env_int("PIGO_REG_WQ", 128) & ~63)) : chunkg[g];
+        const int wq = compress ? std::min(chunkg[g], std::max(64, env_int("PIGO_REG_WQ", 256) & ~63)) : chunkg[g];
         const size_t wave_bytes = (compress ? (size_t)chunkg[g] * 2 : 0) + (size_t)wq * 6 + kRegWavePool * 8;
         for (int pass = 0; pass < 2 && !dropped; ++pass) {
         fixed = (size_t)nh * 64 * 8 + (size_t)(kRegThreads / 64) * wave_bytes + (size_t)deep_cap_g * 8 +
