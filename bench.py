@@ -72,6 +72,7 @@ def parse_args():
                     help="N > 1: all-gather through the C ABI (pigo_run_batch_sharded -> ncclAllGather) or torch.distributed")
     ap.add_argument("--shard-frames", type=int, default=1024,
                     help="frames of the config-3 shard leg (BASELINE configs[2]: 1024 frames per GPU); 0 = skip")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the config-4 (rotated), config-5 (4K) and reference-benchmark legs")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="no GPU: fabricated lists + gloo all-gather; checks the launch / sharding / gather plumbing of --gpus N")
     return ap.parse_args()
@@ -230,6 +231,94 @@ def verify_against_oracle(args, frames, dets, counts, clusters, ccounts, k, what
         if gcl is not None:
             same(gcl[j], wantc[j], f"{what} frame {idx[j]} ClusterDetections")
     return idx
+
+
+def config_leg(args, pg, dev, what, frames_n, steps, verify_k, **over):
+    """One more BASELINE configuration as a side leg of the default line: the same step (RunCascade + ClusterDetections on
+    HBM-resident frames) with other plan parameters, timed over `steps` steps after one warm-up step, `verify_k` frames of the
+    batch checked bit-exactly against the CPU oracle."""
+    import argparse
+    import torch
+    from pigo_amd import batch, synth
+    a2 = argparse.Namespace(**{**vars(args), **over})
+    fr = synth.make_frames(a2.kind, frames_n, a2.rows, a2.cols, seed=a2.seed, first_index=0, rotate_deg=a2.face_rotation)
+    d_fr = torch.from_numpy(fr).to(dev)
+    plan = batch.ScanPlan(pg, a2.rows, a2.cols, MinSize=a2.min_size, MaxSize=a2.max_size, ShiftFactor=a2.shift, ScaleFactor=a2.scale,
+                          angle=a2.angle, max_frames=frames_n, det_cap=a2.det_cap)
+    info = plan.info()
+    dets, counts = plan.alloc_outputs(frames_n)
+    cl = plan.alloc_cluster_outputs(dets, counts)
+
+    def step():
+        plan.run(d_fr, dets, counts)
+        plan.cluster(dets, counts, a2.iou, out=cl)
+
+    step()
+    torch.cuda.synchronize()
+    plan.status()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    plan.status()
+    if int(counts.max().item()) > a2.det_cap:
+        raise SystemExit(f"bench.py: {what}: a frame has {int(counts.max().item())} detections, det_cap is {a2.det_cap}")
+    checked = verify_against_oracle(a2, fr, dets, counts, cl[1], cl[2], verify_k, what=what) if verify_k > 0 else []
+    wpf = int(info.windows_per_frame)
+    leg = {"workload": f"{a2.cols}x{a2.rows} SYN-{a2.kind.upper()}" + (f", faces rotated by {a2.face_rotation} deg" if a2.face_rotation else "") +
+                       f", MinSize={a2.min_size} MaxSize={a2.max_size} Shift={a2.shift} Scale={a2.scale} angle={a2.angle}, {frames_n} HBM-resident frames per step",
+           "frames": frames_n, "steps": steps, "ms_per_step": round(ms, 4), "windows_per_frame": wpf, "variant": int(info.variant),
+           "mwindows_per_s": round(frames_n * wpf / ms / 1e3, 1), "frames_per_s": round(frames_n / ms * 1e3, 1),
+           "detections": int(counts.sum().item()), "clusters": int(cl[2].sum().item()), "verified_frames": checked}
+    del plan, d_fr, dets, counts, cl
+    return leg
+
+
+def reference_benchmark_leg(args, pg):
+    """The reference's own in-tree benchmark, BenchmarkPigoFaceDetection (core/pigo_test.go:96-118): RunCascade + ClusterDetections
+    (IoU 0.1) on testdata/sample.jpg at MinSize 20, MaxSize 1000, ShiftFactor 0.2, ScaleFactor 1.1 -- here on the committed gray
+    fixture of that image (Go's JPEG decoder is not reproducible without Go), one call per iteration through the drop-in
+    single-frame API (host buffer in, host lists out), beside the CPU oracle on the same input."""
+    import oracle
+    from pigo_amd import core, synth
+    gray = synth.sample_gray()
+    rows, cols = gray.shape
+    cp = core.CascadeParams(MinSize=20, MaxSize=1000, ShiftFactor=0.2, ScaleFactor=1.1,
+                            ImageParams=core.ImageParams(Pixels=gray, Rows=rows, Cols=cols, Dim=cols))
+    for _ in range(5):
+        d = pg.RunCascade(cp, 0.0)
+        c = pg.ClusterDetections(d, 0.1)
+    n = 200
+    t = time.perf_counter()
+    for _ in range(n):
+        d = pg.RunCascade(cp, 0.0)
+        c = pg.ClusterDetections(d, 0.1)
+    gpu_ms = (time.perf_counter() - t) / n * 1e3
+    t = time.perf_counter()
+    for _ in range(n):
+        d = pg.RunCascade(cp, 0.0)
+    scan_ms = (time.perf_counter() - t) / n * 1e3
+    orc = oracle.OraclePigo.unpack(synth.facefinder_bytes())
+    want = orc.run_cascade(gray, rows, cols, cols, 20, 1000, 0.2, 1.1, 0.0)
+    wantc = orc.cluster_detections(want.copy(), 0.1)
+    ok = len(d) == len(want) and all((int(a["row"]), int(a["col"]), int(a["scale"]), np.float32(a["q"])) ==
+                                     (int(b["row"]), int(b["col"]), int(b["scale"]), np.float32(b["q"])) for a, b in zip(d, want))
+    ok = ok and len(c) == len(wantc) and all((int(a["row"]), int(a["col"]), int(a["scale"]), np.float32(a["q"])) ==
+                                             (int(b["row"]), int(b["col"]), int(b["scale"]), np.float32(b["q"])) for a, b in zip(c, wantc))
+    if not ok:
+        raise SystemExit("bench.py: VERIFICATION FAILED: reference benchmark leg (sample fixture) differs from the oracle")
+    m = 20
+    t = time.perf_counter()
+    for _ in range(m):
+        w = orc.run_cascade(gray, rows, cols, cols, 20, 1000, 0.2, 1.1, 0.0)
+        orc.cluster_detections(w.copy(), 0.1)
+    cpu_ms = (time.perf_counter() - t) / m * 1e3
+    return {"benchmark": "BenchmarkPigoFaceDetection (core/pigo_test.go:96-118): RunCascade(20/1000/0.2/1.1) + ClusterDetections(0.1), sample fixture "
+                         f"{cols}x{rows}, one call per iteration, host buffers",
+            "gpu_ms_per_op": round(gpu_ms, 4), "gpu_scan_only_ms_per_op": round(scan_ms, 4), "cpu_oracle_ms_per_op": round(cpu_ms, 3),
+            "cpu_kind": "port (C oracle, one thread; a `go test -bench` figure can be put beside gpu_ms_per_op)",
+            "detections": int(len(d)), "clusters": int(len(c)), "verified": True}
 
 
 def torch_index(idx, device):
@@ -529,6 +618,18 @@ def main():
                      "note": "BASELINE configs[2] per-GPU shard (8192 frames / 8 GPUs); its first frames compared with the default batch, its last four with the CPU oracle"}
         del planS, dS, detS, cntS, clS, fS
 
+    # ---- BASELINE configs[3] (rotated scan, angle 0.8: on the benchmark's upright faces and on faces rotated the way that scan
+    # finds them) and configs[4] (4K stress ladder) as side legs, and the reference's own in-tree benchmark -- driver-visible
+    config4_leg = config5_leg = ref_leg = None
+    default_cfg = (args.rows, args.cols, args.angle, args.kind, args.face_rotation) == (1080, 1920, 0.0, "faces", 0.0)
+    if side_legs and default_cfg and not args.no_config_legs:
+        vk = 2 if args.verify_frames > 0 else 0
+        config4_leg = {"upright_faces": config_leg(args, pg, dev, "config-4 leg (upright faces)", 64, 3, vk, angle=0.8),
+                       "rotated_faces": config_leg(args, pg, dev, "config-4 leg (rotated faces)", 64, 3, vk, angle=0.8, face_rotation=-79.0)}
+        config5_leg = config_leg(args, pg, dev, "config-5 leg (4K)", 8, 3, vk, rows=2160, cols=3840, min_size=20, max_size=2000, shift=0.05,
+                                 scale=1.05, det_cap=32768)
+        ref_leg = reference_benchmark_leg(args, pg)
+
     if rank == 0:
         wpf = int(info.windows_per_frame)
         total_frames = n_gpus * B * args.steps
@@ -603,6 +704,9 @@ def main():
             },
         }
         out["config3_shard"] = shard_leg
+        out["config4_rotated"] = config4_leg
+        out["config5_4k"] = config5_leg
+        out["reference_benchmark"] = ref_leg
         out["single_frame"] = single_leg
         out["gray"] = gray_leg
         out["puploc"] = pup_leg

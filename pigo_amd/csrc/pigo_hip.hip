@@ -185,15 +185,11 @@ struct pigo_plan {
     size_t big_lds = 0;
     size_t side_lds = 0;                 // LDS a region workgroup of group 0 leaves to a co-resident side workgroup (0: none reserved)
     bool big_ct = false;                 // the side chain's k_tail_deep reads its codes from global memory (no LDS table)
+    bool big_side_first = false;         // PIGO_BIG_FIRST=1: the side chain is launched before the region groups (default: after the first)
+    int big_skip = 0;                    // PIGO_BIG_SKIP, timing experiments only (results incomplete): 1 = no tail, 2 = no k_scan_big
     std::vector<int> side_splits;        // code windows of the side chain's k_tail_deep launches: [splits[i], splits[i+1])
     bool tile_patch = true;              // variant 3: do the tile classes' survivors include scales <= kPatchMaxS?
     DevBuf<uint32_t> d_tabr;
-    // variant 3, rungs beyond the region groups: survivors binned by position for k_tail_patch
-    bool patch_ok = false;
-    PatchArgs patch{};
-    size_t patch_lds = 0;
-    DevBuf<uint4> d_patch_ent;
-    DevBuf<uint32_t> d_patch_bcount, d_patch_active;
     DevBuf<uint32_t> d_tabp;
     bool tile_ok = false;
     int tab_lds = 0, tab_glb = 0;        // LDS table capacity (trees) of the LDS-pixel / global-pixel classes
@@ -275,8 +271,9 @@ struct pigo_plan {
     }
     size_t workspace_bytes() const
     {
-        return d_scales.bytes() + d_tiles.bytes() + d_tiles2.bytes() + d_tabp.bytes() + d_tab.bytes() + d_queue.bytes() + d_queue2.bytes() + d_qcount.bytes() + d_raw.bytes() + d_flags.bytes() +
-               d_mq.bytes();
+        return d_scales.bytes() + d_tiles.bytes() + d_tiles2.bytes() + d_tabp.bytes() + d_tabr.bytes() + d_tab.bytes() + d_big_items.bytes() + d_queue.bytes() + d_queue2.bytes() +
+               d_qcount.bytes() + d_raw.bytes() + d_flags.bytes() + d_mq.bytes() + d_ties.bytes() + d_cl_seeds.bytes() + d_cl_nseeds.bytes() + d_cl_tmpn.bytes() + d_cl_tmp.bytes() +
+               d_gosort_ws.bytes();
     }
 };
 
@@ -518,6 +515,19 @@ void build_stages(pigo_plan &p, int head_stages_wanted)
 
 int env_int(const char *name, int dflt);
 
+// The two launches of k_tail_deep: the first three passes (192 trees from `lo`; measured plateau 160..256) with their codes in
+// LDS; the few windows that survive them continue in a second launch holding the remaining codes.  false: the codes do not
+// fit one CU's LDS.
+bool set_deep_window(pigo_plan &p, int lo)
+{
+    const int nt = (int)p.c->ntrees;
+    p.args.deep_lo = lo;
+    p.deep_mid = std::min(nt, lo + std::max(64, env_int("PIGO_DEEP_SPLIT", 192)));
+    p.deep_lds = (size_t)(p.deep_mid - lo) * kCodeStride * 4 + (size_t)kDeepWaves * kPatchBytes;
+    p.deep_lds2 = (size_t)(nt - p.deep_mid) * kCodeStride * 4 + (size_t)kDeepWaves * kPatchBytes;
+    return p.deep_lds <= (size_t)(160 << 10) - 1024 && p.deep_lds2 <= (size_t)(160 << 10) - 1024;
+}
+
 // Stages (compaction points) and LDS table windows of k_scan_tile.  A stage never spans more than kTabTrees
 // trees, so the tables of the trees it walks are always resident.
 bool build_tile_stages(pigo_plan &p)
@@ -579,12 +589,7 @@ bool build_tile_stages(pigo_plan &p)
         ends.swap(m);
     }
     a.n_stages = (int)ends.size();
-    // two launches of k_tail_deep: the first three passes (192 trees; measured plateau 160..256) with their codes in LDS;
-    // the few windows that survive them continue in a second launch holding the remaining codes
-    p.deep_mid = std::min(nt, a.deep_lo + std::max(64, env_int("PIGO_DEEP_SPLIT", 192)));
-    p.deep_lds = (size_t)(p.deep_mid - a.deep_lo) * kCodeStride * 4 + (size_t)kDeepWaves * kPatchBytes;
-    p.deep_lds2 = (size_t)(nt - p.deep_mid) * kCodeStride * 4 + (size_t)kDeepWaves * kPatchBytes;
-    if (p.deep_lds > (size_t)(160 << 10) - 1024 || p.deep_lds2 > (size_t)(160 << 10) - 1024) return false;  // codes must fit one CU's LDS
+    if (!set_deep_window(p, a.deep_lo)) return false;
     int hi = 0;  // trees [.., hi) are resident
     for (int st = 0; st < a.n_stages; ++st) {
         const int t0 = st == 0 ? 0 : ends[st - 1] + 1;
@@ -994,6 +999,8 @@ pigo_status build_big(pigo_plan &p)
     // the tail of the side chain: ONE k_tail_deep launch without an LDS code table (CT: codes from the node-major pair table in
     // global memory) over all the remaining trees; PIGO_BIG_CT=0: launches with LDS code windows of PIGO_BIG_DEEP_SPLIT trees
     p.big_ct = env_int("PIGO_BIG_CT", 1) != 0 && c.d_codes_t.p != nullptr;
+    p.big_side_first = env_int("PIGO_BIG_FIRST", 0) != 0;
+    p.big_skip = env_int("PIGO_BIG_SKIP", 0);
     if (nh < nt) {
         const int wmax = p.big_ct ? nt : std::max(64, std::min(600, env_int("PIGO_BIG_DEEP_SPLIT", 192)));
         for (int t = nh; t < nt; t += wmax) p.side_splits.push_back(t);
@@ -1029,6 +1036,20 @@ pigo_status plan_alloc_batch(pigo_plan &p, int max_frames, int det_cap)
     HIP_TRY(p.d_raw.alloc((size_t)det_cap * max_frames));
     HIP_TRY(p.d_mq.alloc((size_t)det_cap * max_frames));
     HIP_TRY(p.d_ties.alloc(max_frames));
+    // ClusterDetections workspaces, sized here so that pigo_plan_cluster never allocates (it may be called while the caller's
+    // stream is being captured): the kernel family is fixed at plan creation -- PIGO_CLUSTER_V2 read once, else by det_cap
+    {
+        const int mode = env_int("PIGO_CLUSTER_V2", -1);
+        p.cluster_mode = mode >= 0 ? (mode != 0 ? 1 : 0) : (det_cap > 4096 ? 1 : 0);
+        if (p.cluster_mode == 1) {
+            const size_t need = (size_t)max_frames * det_cap;
+            HIP_TRY(p.d_cl_seeds.alloc(need));
+            HIP_TRY(p.d_cl_tmpn.alloc(need));
+            HIP_TRY(p.d_cl_tmp.alloc(need));
+            HIP_TRY(p.d_cl_nseeds.alloc(max_frames));
+        }
+        if (det_cap > kGoSortKeys) HIP_TRY(p.d_gosort_ws.alloc((size_t)max_frames * det_cap * 12));  // k_gosort_ties: keys + tie counts of lists beyond the LDS
+    }
     return PIGO_OK;
 }
 
@@ -1078,7 +1099,10 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         hipStream_t s = nullptr;
         ~BuildStream()
         {
-            if (s) (void)hipStreamDestroy(s);
+            if (s) {
+                (void)hipStreamSynchronize(s);  // an early error return must not leave copies from host vectors in flight
+                (void)hipStreamDestroy(s);
+            }
         }
     } bs;
     HIP_TRY(hipStreamCreateWithFlags(&bs.s, hipStreamNonBlocking));
@@ -1145,6 +1169,15 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         // eager launches (profiles/r02_experiments.md); PIGO_GRAPH_FRAMES=n turns it on for batches of up to n frames
         p->graph_max_frames = std::max(0, env_int("PIGO_GRAPH_FRAMES", 0));
         p->region_ok = build_region_groups(*p);
+        {
+            // k_tail_deep's code window starts at the earliest hand-over tree that really occurs: the tile classes' and, with region
+            // groups, each group's (build_tile_stages assumed the mid group's early hand-over, which dense ladders and plans without
+            // region groups do not use -- the window then held trees no queue entry can start at)
+            int lo = std::min(p->args.nh_lds, p->args.nh_glb);
+            if (p->region_ok)
+                for (const pigo_plan::RegionGroup &g : p->regions) lo = std::min(lo, g.args.nh);
+            if (lo > p->args.deep_lo && !set_deep_window(*p, lo)) return fail(PIGO_ERR_PARAM, "tree codes do not fit the LDS");
+        }
         if (p->region_ok) {
             // the region groups' offset tables: k_build_tabp with every rung's pitch set to its group's region pitch
             std::vector<ScaleDesc> sreg(p->scales);
@@ -1179,35 +1212,6 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     }
     st = plan_alloc_batch(*p, max_frames, det_cap);
     if (st != PIGO_OK) return st;
-    // Variant 3, upright: the survivors of the rungs beyond the region groups are binned by position for k_tail_patch
-    // (PIGO_PATCH=0: round 2's late mode + k_tail_deep instead).
-    if (p->region_ok && !p->rot && env_int("PIGO_PATCH", 0) != 0 && nscales <= 2047 && (int)c->ntrees >= kPatchHead && c->ntrees <= 2048) {
-        PatchArgs &P = p->patch;
-        P.cell_log2 = std::max(4, std::min(8, env_int("PIGO_PATCH_CELL_LOG2", 6)));
-        P.ncx = ((key.cols - 1) >> P.cell_log2) + 1;
-        P.nb = P.ncx * (((key.rows - 1) >> P.cell_log2) + 1);
-        P.cap = std::max(8, std::min(kPatchEnt, env_int("PIGO_PATCH_CAP", kPatchEnt)));
-        P.t_hand = std::max(1, env_int("PIGO_PATCH_TREE", 4));
-        P.nscales = nscales;
-        const size_t nbk = (size_t)max_frames * P.nb;
-        P.acap = (uint32_t)std::min<size_t>(nbk, 0xffffffffu);
-        p->patch_lds = (size_t)(160 << 10) - 4096;  // static LDS of k_tail_patch: entries, group record
-        P.pix_bytes = (int32_t)(p->patch_lds - (size_t)kPatchHead * (kCodeStride + 64) * 4 - (size_t)c->ntrees * 4 - (size_t)((c->ntrees + 7) & ~7u) * 2 -
-                                (size_t)((nscales + 7) & ~7) * 2);
-        if (nbk * P.cap < (1ull << 31)) {
-            HIP_TRY(p->d_patch_ent.alloc(nbk * P.cap));
-            HIP_TRY(p->d_patch_bcount.alloc(nbk));
-            HIP_TRY(p->d_patch_active.alloc((size_t)8 * P.acap));
-            HIP_TRY(hipMemsetAsync(p->d_patch_bcount.p, 0, nbk * 4, bs.s));  // (k_tail_patch leaves every bucket it drains empty)
-            HIP_TRY(hipFuncSetAttribute((const void *)k_tail_patch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->patch_lds));
-            P.ent = p->d_patch_ent.p;
-            P.bcount = p->d_patch_bcount.p;
-            P.active = p->d_patch_active.p;
-            P.nactive = nullptr;  // per run: the queue set's counters + 32
-            p->patch_ok = true;
-        }
-    }
-
     ScanArgs &a = p->args;
     a.scales = p->d_scales.p;
     a.tiles = p->d_tiles.p;
@@ -1431,7 +1435,7 @@ void launch_big(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry 
     ba.big = p.big;
     ba.big.next = a.qcount + 40;
     const int per_cu = std::max(1, env_int("PIGO_BIG_PER_CU", 1));
-    static const int skip = env_int("PIGO_BIG_SKIP", 0);  // timing experiments only (results incomplete): 1 = no tail, 2 = no k_scan_big
+    const int skip = p.big_skip;
     mark("scan_big");
     if (!(skip & 2)) k_scan_big<ROT><<<256 * per_cu, kBigThreads, p.big_lds, s>>>(ba);
     static const char *names[] = {"tail_deep", "tail_deep2", "tail_deep3", "tail_deep4", "tail_deep5", "tail_deep6"};
@@ -1498,27 +1502,11 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             ab.qcount = p.d_qcount.p + 16;
             // which launch goes to the hardware first: with the region workgroups resident everywhere (one per CU, the reserve free)
             // a side kernel's 256 workgroups land one per CU; launched into an empty chip the dispatcher may stack them
-            static const bool region_first = env_int("PIGO_BIG_FIRST", 0) == 0;
-            const bool reg_early = region_first && p.big_ok && !p.patch_ok;
+            const bool reg_early = !p.big_side_first && p.big_ok;
             if (reg_early) launch_tiles<ROT, GUARD>(p, ab, xcd_cap, s, mark, true, 1);
-            bool patched = false;
-            if constexpr (!ROT) {
-                if (p.patch_ok) {
-                    // the tile classes bin their survivors by position; k_tail_patch finishes them out of LDS patches (and drains
-                    // the survivor queues, which only hold the entries of overfull buckets then): no k_tail_deep for this set
-                    aa.patch = p.patch;
-                    aa.patch.nactive = p.d_qcount.p + 32;
-                    launch_tiles<ROT, GUARD>(p, aa, xcd_cap, sa, mark, true, 2);
-                    mark("tail_patch");
-                    ScanArgs pa = aa;
-                    pa.qcap = xcd_cap;
-                    k_tail_patch<<<256 * std::max(1, env_int("PIGO_PATCH_PER_CU", 1)), kPatchThreads, p.patch_lds, sa>>>(pa);
-                    patched = true;
-                }
-            }
-            if (!patched && p.big_ok) {
+            if (p.big_ok) {
                 launch_big<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, sa, mark);
-            } else if (!patched) {
+            } else {
                 launch_tiles<ROT, GUARD>(p, aa, xcd_cap, sa, mark, true, 2);
                 launch_tail<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, sa, mark, p.tile_patch);
             }
@@ -1872,17 +1860,9 @@ extern "C" pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, c
     // Lists of a few hundred detections (1080p) are served by one workgroup per frame; plans that can hold long lists (the 4K
     // stress config: thousands of detections, hundreds of clusters per frame) by the seeds / members / compact kernels, which
     // spread a frame's clusters over the chip and have no length limit.  PIGO_CLUSTER_V2=0/1 forces one.
-    const int mode = p->cluster_mode >= 0 ? p->cluster_mode : env_int("PIGO_CLUSTER_V2", -1);
-    const bool v2 = mode >= 0 ? mode != 0 : p->det_cap > 4096;
+    // (the family and its workspaces are fixed at plan creation: plan_alloc_batch)
+    const bool v2 = p->cluster_mode == 1;
     if (!v2 && p->det_cap > 65536) return fail(PIGO_ERR_PARAM, "k_cluster supports det_cap <= 65536 (PIGO_CLUSTER_V2=0 was forced)");
-    if (v2) {
-        std::lock_guard<std::mutex> lock(p->mu);
-        const size_t need = (size_t)p->max_frames * p->det_cap;
-        if (p->d_cl_seeds.n < need) HIP_TRY(p->d_cl_seeds.alloc(need));
-        if (p->d_cl_tmpn.n < need) HIP_TRY(p->d_cl_tmpn.alloc(need));
-        if (p->d_cl_tmp.n < need) HIP_TRY(p->d_cl_tmp.alloc(need));
-        if (p->d_cl_nseeds.n < (size_t)p->max_frames) HIP_TRY(p->d_cl_nseeds.alloc(p->max_frames));
-    }
     if (!d_ties) d_ties = p->d_ties.p;
     HIP_TRY(hipMemsetAsync(d_ties, 0, (size_t)nframes * 4, s));
     dim3 grid((unsigned)((p->det_cap + kThreads - 1) / kThreads), (unsigned)nframes);
@@ -1902,11 +1882,6 @@ extern "C" pigo_status pigo_plan_cluster(pigo_plan *p, const pigo_det *d_dets, c
         if (!p->gosort_attr) {
             HIP_TRY(hipFuncSetAttribute((const void *)k_gosort_ties, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_fixed + (size_t)kGoSortKeys * 10)));
             p->gosort_attr = true;
-        }
-        if (p->det_cap > kGoSortKeys) {  // lists that do not fit the LDS keep their keys and tie counts here
-            std::lock_guard<std::mutex> lock(p->mu);
-            const size_t need = (size_t)p->max_frames * p->det_cap * 12;
-            if (p->d_gosort_ws.n < need) HIP_TRY(p->d_gosort_ws.alloc(need));
         }
         k_gosort_ties<<<nframes, gosort::kSortThreads, lds_fixed + (size_t)lds_keys * 10, s>>>(d_dets, d_counts, p->det_cap, d_ties, d_sorted, lds_keys,
                                                                                               p->det_cap > kGoSortKeys ? p->d_gosort_ws.p : nullptr);

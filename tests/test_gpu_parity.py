@@ -633,13 +633,14 @@ def test_region_deep_list_spill_goes_through_the_tail(pg, orc, monkeypatch):
     assert sum(len(w) for w in want) > 200
 
 
-@pytest.mark.parametrize("env", [{"PIGO_PATCH": "0"}, {"PIGO_PATCH_CAP": "8"}, {"PIGO_PATCH_CELL_LOG2": "8", "PIGO_PATCH_TREE": "1"},
-                                 {"PIGO_PATCH_CELL_LOG2": "4", "PIGO_PATCH_TREE": "9"}])
-def test_big_scale_patches_buckets_overflow_and_the_old_path(pg, orc, env, monkeypatch):
-    """The big scales of a variant-3 plan: k_scan_tile bins their survivors by position, k_tail_patch finishes them out of LDS
-    patches.  Forced here: round 2's path without buckets (late mode + k_tail_deep), buckets of 8 entries (overfull ones
-    spill into the survivor queue, which k_tail_patch drains from global memory), 256-pixel cells with the hand-over right
-    after tree 0 (groups that do not fit one patch are split; long lists per bucket), 16-pixel cells with a late hand-over.
+@pytest.mark.parametrize("env", [{}, {"PIGO_BIG": "0"}, {"PIGO_BIG_CT": "0"}, {"PIGO_BIG_CT": "0", "PIGO_BIG_DEEP_SPLIT": "96"},
+                                 {"PIGO_REG_RESERVE0_KB": "0", "PIGO_BIG_FIRST": "1"}, {"PIGO_BIG_POOL_TREE": "2", "PIGO_NH_GLB": "28"},
+                                 {"PIGO_BIG_MERGE": "0", "PIGO_REG_COMPRESS": "0"}, {"PIGO_REG_WQ": "64", "PIGO_REG_RESERVE1_KB": "16"}])
+def test_big_scales_side_chain_and_its_switches(pg, orc, env, monkeypatch):
+    """The scales above the region groups of a variant-3 plan: k_scan_big (persistent, next to the region workgroups) + k_tail_deep
+    without an LDS code table.  Forced here: the default; round 3's tile class instead (PIGO_BIG=0); the tail with LDS code
+    windows, two launches and five; no LDS reserve with the side chain launched first; pool from tree 2 with the hand-over at
+    tree 28; unmerged chunk stages next to an uncompressed region queue; 64-entry region queues with a reserve in both groups.
     Every frame against the oracle, raw lists bit-exact.  core/pigo.go:113-147, :212-258."""
     import threading
     import torch
@@ -660,15 +661,23 @@ def test_big_scale_patches_buckets_overflow_and_the_old_path(pg, orc, env, monke
     assert int(plan.info().variant) == 3
     d_frames = torch.from_numpy(frames).cuda()
     dets, counts = plan.alloc_outputs(n)
-    for rep in range(2):  # the second run finds every bucket empty again
+    for rep in range(2):  # (the second run starts from the counters the first one left)
         plan.run(d_frames, dets, counts)
     torch.cuda.synchronize()
     plan.status()
+    plan.set_profiling(True)  # the per-kernel timing pass runs the same launches on one stream
+    plan.run(d_frames, dets, counts)
+    torch.cuda.synchronize()
+    names = [k for k, _ in plan.last_timings()]
+    plan.set_profiling(False)
+    assert ("scan_big" in names) == (env.get("PIGO_BIG") != "0"), names
+    if env.get("PIGO_BIG_DEEP_SPLIT") == "96":
+        assert "tail_deep5" in names, names
     for t in th:
         t.join()
     got = batch.dets_to_numpy(dets, counts)
     for f in range(n):
-        assert_same_dets(got[f], want[f], f"patch path {env} frame {f}", Q_TOL_RAW)
+        assert_same_dets(got[f], want[f], f"big-scale path {env} frame {f}", Q_TOL_RAW)
     assert sum(len(w) for w in want) > 300
 
 
