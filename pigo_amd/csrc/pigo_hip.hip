@@ -966,7 +966,9 @@ pigo_status build_big(pigo_plan &p)
     const int kbig = p.regions.back().args.k_hi;
     if (kbig >= nscales) return PIGO_OK;
     // hand-over tree: right behind a stage end, as for the tile classes (48 for the facefinder: the next real threshold after 27)
-    int nh = std::min(a.nh_glb, std::min(nt, kTabTrees));
+    // (plans of a few frames are latency-bound: a pooled window walks its trees one after the other, 18 dependent round trips to
+    // memory per pool step, so there the pool only finishes the cascade's first stages and lane = tree takes over at tree 4)
+    int nh = std::min(env_int("PIGO_NH_BIG", p.max_frames >= 8 ? a.nh_glb : 4), std::min(nt, kTabTrees));
     {
         bool at_end = nh == nt;
         for (int st = 0; st < a.n_stages; ++st) at_end = at_end || a.st_end[st] + 1 == nh;
