@@ -231,6 +231,8 @@ struct pigo_plan {
     hipStream_t side2[3] = {nullptr, nullptr, nullptr};  // PIGO_SIDE_STREAM=2: every tile class on its own stream
     hipEvent_t ev_join2[3] = {nullptr, nullptr, nullptr};
     int side_mode = 1;
+    int fork_min_frames = 8;             // batches of at least this many frames run their tile classes on separate streams
+    bool small_ct = false;               // plans of a few frames: k_tail_deep as one table-free launch (launch_tail)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t grp_stream = nullptr;    // variant 3, small batches: the second region group runs next to the first
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
@@ -840,7 +842,12 @@ bool build_region_groups(pigo_plan &p)
         // counts the region's windows and, if the list is short for them, pass 1 sizes again with a longer one (<= 2048 entries:
         // the LDS it takes comes out of the cell).
         const size_t max_dyn = max_dyn_all - reserve_g[g];
-        int deep_cap_g = deepg[g];
+        // (plans of a few frames are latency-bound: a face keeps ~100 windows of ONE region alive through all 468 trees, and the 16
+        // waves of that region's workgroup would finish them in three rounds of ~12 dependent passes while the rest of the chip
+        // idles -- there every window that passes the hand-over tree goes to k_tail_deep's queue instead, one wave per window
+        // over the whole chip: no deep list)
+        const bool no_deep_list = p.max_frames < 8 && env_int("PIGO_REG_DEEP_SMALL", 0) == 0;
+        int deep_cap_g = no_deep_list ? 0 : deepg[g];
         const double deep_per_window[NG] = {0.0125, 0.026, 0.026};  // (the 1080p config: 81 k windows -> 1024, 6 k -> the 512 minimum)
         const bool deep_fixed = getenv(g == 0 ? "PIGO_REG_DEEP0" : g == 1 ? "PIGO_REG_DEEP1" : "PIGO_REG_DEEP2") != nullptr;
         size_t fixed = 0;
@@ -902,7 +909,7 @@ bool build_region_groups(pigo_plan &p)
                 again = true;
             }
             const int want = std::min(2048, (int)((wins * deep_per_window[g] + 255) / 256) * 256);
-            if (!deep_fixed && want > deep_cap_g) {
+            if (!deep_fixed && !no_deep_list && want > deep_cap_g) {
                 deep_cap_g = want;
                 again = true;
             }
@@ -1145,6 +1152,8 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, true, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         p->tile_threads = env_int("PIGO_TILE_THREADS", 256) == 512 ? 512 : 256;
         p->side_mode = env_int("PIGO_SIDE_STREAM", 1);
+        p->fork_min_frames = std::max(1, env_int("PIGO_FORK_MIN_FRAMES", 1));
+        p->small_ct = max_frames < 8 && c->d_codes_t.p != nullptr && env_int("PIGO_SMALL_CT", 1) != 0;
         if (p->side_mode == 2)
             for (int i = 0; i < 3; ++i) {
                 HIP_TRY(hipStreamCreateWithFlags(&p->side2[i], hipStreamNonBlocking));
@@ -1313,7 +1322,7 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
     for (const pigo_plan::TileClass &cls : p.classes)
         if (cls.ntiles - (v3 ? cls.v3_skip : 0u)) (cls.lds ? has_lds : has_glb) = true;
     // (a small batch is launch-bound: every fork / join costs more than the overlap buys -- one stream then)
-    const bool fork = p.side && has_lds && has_glb && !p.profiling && a.nframes >= 8;
+    const bool fork = p.side && has_lds && has_glb && !p.profiling && a.nframes >= p.fork_min_frames;
     const bool fork_all = fork && p.side_mode == 2;
     if (fork) {
         (void)hipEventRecord(p.ev_fork, s);
@@ -1390,6 +1399,26 @@ void launch_tail(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(cu_max, (size_t)(158 << 10) / std::max<size_t>(lds1, 1)));
     const int per_cu2 = (int)std::max<size_t>(1, std::min<size_t>(nop ? cu_max : 1, (size_t)(158 << 10) / std::max<size_t>(lds2, 1)));
     if (a.deep_lo >= a.ntrees) return;
+    if (p.small_ct) {
+        // plans of a few frames: ONE launch over all the remaining trees, codes from the node-major pair table in global memory --
+        // no 50 KiB code copy per workgroup, no second launch behind a queue round trip (the call's latency is what counts there)
+        mark("tail_deep");
+        ScanArgs ta = a;
+        ta.qcap = xcd_cap;
+        ta.nqueues = 8;
+        ta.deep_hi = a.ntrees;
+        ta.queue2 = nullptr;
+        ta.qcount2 = nullptr;
+        ta.qcap2 = 0;
+        const int per = std::max(1, env_int("PIGO_SMALL_CT_PER_CU", 2));
+        if constexpr (ROT)
+            k_tail_deep<true, GUARD, false, true><<<256 * per, kDeepThreads, 0, s>>>(ta);
+        else
+            k_tail_deep<false, false, false, true><<<256 * per, kDeepThreads, 0, s>>>(ta);
+        (void)queue2;
+        (void)cap2;
+        return;
+    }
     mark("tail_deep");
     ScanArgs ta = a;
     ta.qcap = xcd_cap;
@@ -1962,10 +1991,22 @@ extern "C" pigo_status pigo_cluster_detections(pigo_cascade *c, pigo_det *dets, 
 namespace {
 
 // enqueue one RunCascade on the slot's stream: upload, scan, download of the count, the status flags and the detections
-pigo_status slot_enqueue(pigo_cascade::RunSlot &sl)
+// `pixels` != nullptr: the caller's frame goes through the pinned staging buffer in pieces, each piece's upload in flight while
+// the next one is copied (the frame's 2 MB cost one host memcpy + one PCIe transfer back to back otherwise); nullptr: the
+// staging buffer already holds the frame (graph capture).
+pigo_status slot_enqueue(pigo_cascade::RunSlot &sl, const uint8_t *pixels = nullptr)
 {
     pigo_plan *p = sl.plan.get();
-    HIP_TRY(hipMemcpyAsync(sl.d_frame.p, sl.h_frame, sl.fbytes, hipMemcpyHostToDevice, sl.stream));
+    if (pixels) {
+        static const size_t piece = (size_t)std::max(64, env_int("PIGO_UPLOAD_PIECE_KB", 512)) << 10;
+        for (size_t off = 0; off < sl.fbytes; off += piece) {
+            const size_t nb = std::min(piece, sl.fbytes - off);
+            memcpy(sl.h_frame + off, pixels + off, nb);
+            HIP_TRY(hipMemcpyAsync(sl.d_frame.p + off, sl.h_frame + off, nb, hipMemcpyHostToDevice, sl.stream));
+        }
+    } else {
+        HIP_TRY(hipMemcpyAsync(sl.d_frame.p, sl.h_frame, sl.fbytes, hipMemcpyHostToDevice, sl.stream));
+    }
     pigo_status st = plan_run_variant(p, sl.d_frame.p, sl.fbytes, 1, sl.d_dets.p, sl.d_count.p, sl.stream, p->variant);
     if (st != PIGO_OK) return st;
     HIP_TRY(hipMemcpyAsync(sl.h_small, sl.d_count.p, 4, hipMemcpyDeviceToHost, sl.stream));
@@ -2053,12 +2094,13 @@ extern "C" pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, 
             }
         } release{c, sl};
         pigo_plan *p = sl->plan.get();
-        memcpy(sl->h_frame, pixels, fbytes);
         pigo_status st = PIGO_OK;
-        if (sl->exec)
+        if (sl->exec) {
+            memcpy(sl->h_frame, pixels, fbytes);
             HIP_TRY(hipGraphLaunch(sl->exec, sl->stream));
-        else
-            st = slot_enqueue(*sl);
+        } else {
+            st = slot_enqueue(*sl, pixels);
+        }
         if (st != PIGO_OK) return st;
         HIP_TRY(hipStreamSynchronize(sl->stream));
         int32_t n = sl->h_small[0];

@@ -1,0 +1,15 @@
+# phase timers of the region groups on a ONE-frame plan (debug build)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python -m pigo_amd.build --debug > /dev/null 2>&1
+B="python bench.py --frames 1 --steps 20 --warmup 2 --no-cpu-baseline --no-gray --shard-frames 0 --no-single-frame --verify-frames 0 --no-kernel-times --variant 3"
+for spec in "g0:PIGO_REG_ONLY=0" "g1:PIGO_REG_ONLY=1" ${EXTRA:-}; do
+  name="${spec%%:*}"; envs="${spec#*:}"
+  echo "== $name"
+  env PIGO_HIP_LIB=$GRAFT_REPO_ROOT/pigo_amd/csrc/libpigo_hip_debug.so PIGO_DEBUG_STATS=1 $envs $B 2>&1 >/dev/null | grep "debug_stats raw" | python -c "
+import sys,ast
+for l in sys.stdin:
+    st=ast.literal_eval(l.split('raw:')[1].strip())
+    reg=max(st[4],1)
+    print('regions %d | per region (cycles): copy %.0f scan %.0f wait %.0f deep(per wave) %.0f total %.0f | deep windows/region %.1f passes/window %.2f' % (st[4], st[0]/reg, st[1]/reg, st[3]/reg, st[2]/reg/16, st[5]/reg, st[7]/reg, st[6]/max(st[7],1)))
+"
+done
