@@ -282,6 +282,8 @@ class Comm {
         return w;
     }
     bool UsesRccl() const { return pigo_comm_uses_rccl(h_.get()) != 0; }
+    // ncclCommAbort: a peer failed and the all-gather would never complete; the object can only be destroyed afterwards
+    void Abort() { detail::check(pigo_comm_abort(h_.get()), "pigo_comm_abort"); }
     pigo_comm *handle() const { return h_.get(); }
 
   private:

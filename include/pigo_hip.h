@@ -261,14 +261,22 @@ pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n);
  * pigo_comm_unique_id) builds a real one-rank RCCL communicator and pigo_run_batch_sharded goes through ncclAllGather exactly
  * as on a multi-GPU node -- the way to exercise the collective on a single-GPU box (pigo_comm_uses_rccl tells which).
  * Errors: a rank whose scan fails inside pigo_run_batch_sharded still contributes zero-count padding rows to the collective
- * before it returns the error, so its peers do not hang; a failure of pigo_comm_init or of the collective itself is fatal for
- * the communicator on every rank (destroy it and start over). */
+ * before it returns the error, so its peers do not hang.  Only SYNCHRONOUS refusals take that path (bad arguments, a launch
+ * error): survivor-queue overflow and lists truncated at det_cap are raised on the device and reported by pigo_plan_status()
+ * after the stream has been synchronised -- every rank must check it (a truncated list also shows in its wire row: the count
+ * word holds the TRUE count).  pigo_comm_init waits for its peers with a deadline (PIGO_COMM_INIT_TIMEOUT_S, default 300 s,
+ * 0 = none) and returns PIGO_ERR_HIP when a peer does not join; a failed pigo_comm_init or collective is fatal for the
+ * communicator on every rank: pigo_comm_abort (if a collective may be outstanding), pigo_comm_destroy, start over. */
 typedef struct pigo_comm pigo_comm;
 #define PIGO_COMM_ID_BYTES 128
 pigo_status pigo_comm_unique_id(uint8_t id[PIGO_COMM_ID_BYTES]);
 pigo_status pigo_comm_init(const uint8_t id[PIGO_COMM_ID_BYTES], int rank, int world, int device, pigo_comm **out);
 pigo_status pigo_comm_info(const pigo_comm *c, int *rank, int *world);
 int pigo_comm_uses_rccl(const pigo_comm *c); /* 1: the all-gather is ncclAllGather; 0: world == 1 without an id, a plain copy */
+/* ncclCommAbort: give up the communicator WITHOUT waiting for outstanding collectives -- for a host whose peer rank has failed
+ * (its pigo_run_batch_sharded all-gather would never complete).  May be called from another thread than the one blocked on the
+ * stream.  Afterwards the handle only accepts pigo_comm_destroy. */
+pigo_status pigo_comm_abort(pigo_comm *c);
 void pigo_comm_destroy(pigo_comm *c);
 /* contiguous shard [lo, hi) of `nframes` frames for `rank`; earlier ranks take the remainder */
 void pigo_shard_bounds(int nframes, int rank, int world, int *lo, int *hi);

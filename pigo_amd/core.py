@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "pigo_rgb_to_grayscale", "pigo_gray_batch",
     "pigo_puploc_create", "pigo_puploc_info", "pigo_puploc_destroy", "pigo_puploc_run_detector", "pigo_get_landmark_point",
     "pigo_puploc_run_batch", "pigo_puploc_status",
-    "pigo_comm_unique_id", "pigo_comm_init", "pigo_comm_info", "pigo_comm_uses_rccl", "pigo_comm_destroy", "pigo_shard_bounds", "pigo_wire_words",
+    "pigo_comm_unique_id", "pigo_comm_init", "pigo_comm_info", "pigo_comm_uses_rccl", "pigo_comm_abort", "pigo_comm_destroy", "pigo_shard_bounds", "pigo_wire_words",
     "pigo_run_batch_sharded", "pigo_pack_lists", "pigo_unpack_list",
 ]
 
@@ -141,6 +141,7 @@ def load_library():
     L.pigo_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     L.pigo_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.pigo_comm_uses_rccl.argtypes = [vp]
+    L.pigo_comm_abort.argtypes = [vp]
     L.pigo_comm_destroy.argtypes = [vp]
     L.pigo_comm_destroy.restype = None
     L.pigo_shard_bounds.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]

@@ -2410,6 +2410,10 @@ extern "C" pigo_status pigo_get_landmark_point(pigo_puploc_cascade *c, const pig
 // the end.  librccl is bound at run time (dlopen) so that single-GPU users of libpigo_hip.so do not need it.
 
 #include <dlfcn.h>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <thread>
 
 namespace {
 
@@ -2420,6 +2424,7 @@ typedef void *rccl_comm_t;
 typedef int (*fn_ncclGetUniqueId)(RcclUniqueId *);
 typedef int (*fn_ncclCommInitRank)(rccl_comm_t *, int, RcclUniqueId, int);
 typedef int (*fn_ncclCommDestroy)(rccl_comm_t);
+typedef int (*fn_ncclCommAbort)(rccl_comm_t);
 typedef int (*fn_ncclAllGather)(const void *, void *, size_t, int, rccl_comm_t, hipStream_t);
 typedef const char *(*fn_ncclGetErrorString)(int);
 constexpr int kNcclInt32 = 2;  // ncclDataType_t: ncclInt8 0, ncclUint8 1, ncclInt32 2 (rccl.h)
@@ -2429,6 +2434,7 @@ struct Rccl {
     fn_ncclGetUniqueId get_id = nullptr;
     fn_ncclCommInitRank init_rank = nullptr;
     fn_ncclCommDestroy destroy = nullptr;
+    fn_ncclCommAbort abort = nullptr;
     fn_ncclAllGather all_gather = nullptr;
     fn_ncclGetErrorString err = nullptr;
 };
@@ -2451,6 +2457,7 @@ pigo_status rccl_load(const Rccl **out)
         r.get_id = (fn_ncclGetUniqueId)dlsym(h, "ncclGetUniqueId");
         r.init_rank = (fn_ncclCommInitRank)dlsym(h, "ncclCommInitRank");
         r.destroy = (fn_ncclCommDestroy)dlsym(h, "ncclCommDestroy");
+        r.abort = (fn_ncclCommAbort)dlsym(h, "ncclCommAbort");
         r.all_gather = (fn_ncclAllGather)dlsym(h, "ncclAllGather");
         r.err = (fn_ncclGetErrorString)dlsym(h, "ncclGetErrorString");
         if (!r.get_id || !r.init_rank || !r.destroy || !r.all_gather) return fail(PIGO_ERR_HIP, "librccl lacks a required symbol");
@@ -2471,6 +2478,7 @@ pigo_status rccl_load(const Rccl **out)
 struct pigo_comm {
     int rank = 0, world = 1, device = 0;
     rccl_comm_t comm = nullptr;  // NULL when world == 1: nothing to exchange
+    bool aborted = false;        // pigo_comm_abort was called: every further collective on it is refused
 };
 
 extern "C" pigo_status pigo_comm_unique_id(uint8_t id[PIGO_COMM_ID_BYTES])
@@ -2506,9 +2514,58 @@ extern "C" pigo_status pigo_comm_init(const uint8_t id[PIGO_COMM_ID_BYTES], int 
         HIP_TRY(hipSetDevice(device));
         RcclUniqueId u;
         memcpy(u.internal, id, PIGO_COMM_ID_BYTES);
-        RCCL_TRY(r, r->init_rank(&c->comm, world, u, rank));
+        // ncclCommInitRank blocks until EVERY rank has called it: a peer that died on the way here (no device, bad plan, crashed
+        // process) would hang this rank forever.  The call therefore runs on a helper thread and this one waits for it with a
+        // deadline (PIGO_COMM_INIT_TIMEOUT_S, default 300 s; 0 = wait in place, no deadline).  After a timeout the communicator
+        // is unusable and the helper thread stays blocked inside RCCL: the host reports the error and ends the process.
+        const int timeout_s = std::max(0, env_int("PIGO_COMM_INIT_TIMEOUT_S", 300));
+        if (timeout_s == 0) {
+            RCCL_TRY(r, r->init_rank(&c->comm, world, u, rank));
+        } else {
+            struct InitState {
+                std::mutex mu;
+                std::condition_variable cv;
+                bool done = false;
+                int rc = 0;
+                rccl_comm_t comm = nullptr;
+            };
+            std::shared_ptr<InitState> stt = std::make_shared<InitState>();
+            const fn_ncclCommInitRank init = r->init_rank;
+            std::thread([stt, init, world, u, rank, device]() {
+                (void)hipSetDevice(device);
+                rccl_comm_t cm = nullptr;
+                const int rc = init(&cm, world, u, rank);
+                std::lock_guard<std::mutex> lock(stt->mu);
+                stt->rc = rc;
+                stt->comm = cm;
+                stt->done = true;
+                stt->cv.notify_all();
+            }).detach();
+            std::unique_lock<std::mutex> lock(stt->mu);
+            if (!stt->cv.wait_for(lock, std::chrono::seconds(timeout_s), [&] { return stt->done; }))
+                return fail(PIGO_ERR_HIP, "pigo_comm_init: rank %d of %d waited %d s for its peers in ncclCommInitRank (PIGO_COMM_INIT_TIMEOUT_S); "
+                                          "a peer did not join -- this communicator cannot be used", rank, world, timeout_s);
+            if (stt->rc != 0) return fail(PIGO_ERR_HIP, "ncclCommInitRank: %s", r->err ? r->err(stt->rc) : "rccl error");
+            c->comm = stt->comm;
+        }
     }
     *out = c.release();
+    return PIGO_OK;
+}
+
+// ncclCommAbort: frees the communicator WITHOUT waiting for its outstanding collectives -- what a host calls (from any thread)
+// when a peer has failed and pigo_run_batch_sharded's all-gather would otherwise never complete.  The handle stays valid for
+// pigo_comm_destroy only.
+extern "C" pigo_status pigo_comm_abort(pigo_comm *c)
+{
+    if (!c) return fail(PIGO_ERR_PARAM, "comm is NULL");
+    if (!c->comm) return PIGO_OK;  // world 1 without an id: nothing in flight
+    if (!g_rccl.abort) return fail(PIGO_ERR_HIP, "librccl has no ncclCommAbort");
+    (void)hipSetDevice(c->device);
+    const int rc = g_rccl.abort(c->comm);
+    c->comm = nullptr;
+    c->aborted = true;
+    if (rc != 0) return fail(PIGO_ERR_HIP, "ncclCommAbort: %s", g_rccl.err ? g_rccl.err(rc) : "rccl error");
     return PIGO_OK;
 }
 
@@ -2584,6 +2641,7 @@ extern "C" pigo_status pigo_run_batch_sharded(pigo_plan *p, pigo_comm *comm, con
     if (gather_cap < 1 || gather_cap > p->det_cap) return fail(PIGO_ERR_PARAM, "gather_cap outside [1, det_cap]");
     if (!d_gathered) return fail(PIGO_ERR_PARAM, "d_gathered is NULL");
     const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
+    if (comm && comm->aborted) return fail(PIGO_ERR_PARAM, "the communicator was aborted (pigo_comm_abort): destroy it and build a new one");
     if (comm && comm->device != p->c->device) return fail(PIGO_ERR_PARAM, "communicator and plan live on different devices");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(p->c->device));

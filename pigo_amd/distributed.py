@@ -63,6 +63,10 @@ class Comm:
         if h and core._lib is not None:
             core._lib.pigo_comm_destroy(h)
 
+    def abort(self):
+        """pigo_comm_abort (ncclCommAbort): give the communicator up without waiting for outstanding collectives -- a peer failed."""
+        core.check(self.L.pigo_comm_abort(self._h), "comm_abort")
+
     @staticmethod
     def unique_id() -> bytes:
         buf = (C.c_uint8 * 128)()

@@ -133,6 +133,33 @@ def test_bench_spawns_its_own_ranks():
     assert d["n_gpus"] == 2 and d["dry_run"] is True and d["ranks_seen"] == [0, 1] and d["gathered_rows"] == 10
 
 
+def test_bench_dry_run_world8_config3_shard_rows():
+    """BASELINE configs[2] as the driver launches it -- 8 ranks, 1,024 frames per rank -- without GPUs: every rank fabricates its
+    shard's lists, the gathered tensor must hold 8 x 1,024 rows with rank r's frames at rows [1024 r, 1024 (r + 1)) in frame
+    order and the true counts (also those above the gather capacity) in the count word."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--cpu-dry-run", "--steps", "1", "--warmup", "0",
+                        "--frames", "1024"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["dry_run"] is True and d["ranks_seen"] == list(range(8))
+    assert d["gathered_rows"] == 8192 and d["gather_ok"] is True
+
+
+def test_comm_abort_on_a_plain_handle_and_header_declares_it():
+    """pigo_comm_abort exists in the C ABI (include/pigo_hip.h) and is a no-op on a world-1 handle without RCCL."""
+    c = distributed.Comm(0, 1, 0)
+    c.abort()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert "pigo_status pigo_comm_abort(pigo_comm *c);" in open(os.path.join(root, "include", "pigo_hip.h")).read()
+
+
 def test_pack_unpack_roundtrip():
     dets, counts = _fake_lists(0, 5, 12)
     wire = distributed.pack_lists(dets, counts, 8)

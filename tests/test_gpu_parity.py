@@ -5,6 +5,8 @@ implementation targets 0 ulp, so raw-detection q is compared bit-for-bit (Q_TOL_
 a float32 sum reproduced in the reference's order, likewise; the 1e-5 contract tolerance is asserted
 separately so a future relaxation of the design target does not silently weaken the contract.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -734,6 +736,35 @@ def test_sharded_rank_with_a_failing_scan_still_joins_the_collective(pg):
     torch.cuda.synchronize()
     plan.status()
     assert int(wire[:, 0].sum()) > 0
+
+
+def test_comm_abort_and_init_deadline(pg, monkeypatch):
+    """pigo_comm_abort (ncclCommAbort) on a real one-rank RCCL communicator: the handle refuses further collectives and can
+    still be destroyed; and pigo_comm_init's deadline: a rank whose peer never calls ncclCommInitRank gets PIGO_ERR_HIP back
+    after PIGO_COMM_INIT_TIMEOUT_S instead of hanging (world 2, only rank 0 shows up)."""
+    import time
+    import torch
+    from pigo_amd import batch, distributed
+    n, rows, cols, gcap = 4, 270, 480, 8
+    d_frames = torch.from_numpy(synth.make_frames("faces", n, rows, cols, seed=5)).cuda()
+    plan = batch.ScanPlan(pg, rows, cols, max_frames=n, det_cap=256)
+    comm = distributed.Comm(0, 1, 0, distributed.Comm.unique_id())
+    assert comm.uses_rccl
+    wire = distributed.run_batch_sharded(plan, comm, d_frames, n, 0.2, gcap)
+    torch.cuda.synchronize()
+    plan.status()
+    assert int(wire[:, 0].sum()) > 0
+    comm.abort()
+    with pytest.raises(ValueError):
+        distributed.run_batch_sharded(plan, comm, d_frames, n, 0.2, gcap)
+    del comm
+    if os.environ.get("PIGO_TEST_COMM_DEADLINE") != "1":
+        return  # (the timed-out rank's helper thread stays blocked inside RCCL until the process ends: run on request only)
+    monkeypatch.setenv("PIGO_COMM_INIT_TIMEOUT_S", "3")
+    t0 = time.time()
+    with pytest.raises(core.PigoError):
+        distributed.Comm(0, 2, 0, distributed.Comm.unique_id())
+    assert 2.0 < time.time() - t0 < 60.0
 
 
 def batch_lists_to_host(lists, n):
