@@ -85,7 +85,7 @@ pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, size_t npix
 /* ---- (*Pigo).ClusterDetections, core/pigo.go:262-308 ---------------------------------------------
  * Sorts `dets` in place by ascending Q exactly like the reference's sort.Slice (Go's pdqsort,
  * restated host-side), then runs the IoU clustering on the GPU.  `out` needs room for up to n
- * clusters.  n <= 65536. */
+ * clusters.  No limit on n (lists beyond 2048 entries take the seeds / members / compact kernels). */
 pigo_status pigo_cluster_detections(pigo_cascade *c, pigo_det *dets, int n, double iou_threshold, pigo_det *out, int cap,
                                     int *n_out);
 /* The sort step alone (host): sort.Slice(dets, func(i, j) bool { return dets[i].Q < dets[j].Q }), pigo.go:264 */
@@ -186,8 +186,9 @@ pigo_status pigo_plan_info(const pigo_plan *p, pigo_plan_info_t *info);
  *   2 = one workgroup takes a tile of windows through the whole cascade out of an LDS copy of the tile's
  *       pixels (default when the cascade has depth 6),
  *   3 = one workgroup per CU owns an LDS-resident region of a frame for a whole group of scales (k_scan_region); the
- *       scales above the groups go through variant 2's kernels.  Default for upright plans with dim % 4 == 0 and
- *       max_frames >= 8; PIGO_ERR_PARAM for plans it cannot serve (rotated scans, other strides).
+ *       scales above the groups go through k_scan_big (persistent, next to the region workgroups) and k_tail_deep.  Default
+ *       for plans with dim % 4 == 0 and max_frames >= 8, upright and rotated (landscape frames); PIGO_ERR_PARAM for plans
+ *       it cannot serve (other strides, rotated scans of portrait frames).
  * All variants produce identical results. */
 pigo_status pigo_plan_set_variant(pigo_plan *p, int variant);
 

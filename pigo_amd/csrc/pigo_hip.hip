@@ -49,6 +49,7 @@ pigo_status fail(pigo_status st, const char *fmt, ...)
     } while (0)
 
 int env_int(const char *name, int dflt);
+const char *tune_env(const char *name);
 
 template <class T>
 struct DevBuf {
@@ -193,9 +194,7 @@ struct pigo_plan {
     DevBuf<uint32_t> d_tabp;
     bool tile_ok = false;
     int tab_lds = 0, tab_glb = 0;        // LDS table capacity (trees) of the LDS-pixel / global-pixel classes
-    int tile_threads = 256;              // workgroup size of the LDS-pixel classes of k_scan_tile (256 or 512)
     bool rot_lds = false;                // rotated scan out of LDS tiles (landscape frames: the column clamp nrows-1 stays inside a row)
-    bool tab_global = false;             // LDS-pixel classes read their offset tables from global memory (L1) instead of LDS
     size_t deep_lds = 0, deep_lds2 = 0;  // dynamic LDS of the two k_tail_deep launches
     int deep_mid = 0;                    // first launch walks [deep_lo, deep_mid), second [deep_mid, ntrees)
     int nh_reg_mid = 0;                  // variant 3: the mid scale group's hand-over tree (the small group's is nh_lds)
@@ -228,8 +227,6 @@ struct pigo_plan {
     std::mutex mu;
     // the global-gather tile classes (vector-memory bound) run on a side stream next to the LDS-tile classes (LDS bound)
     hipStream_t side = nullptr;
-    hipStream_t side2[3] = {nullptr, nullptr, nullptr};  // PIGO_SIDE_STREAM=2: every tile class on its own stream
-    hipEvent_t ev_join2[3] = {nullptr, nullptr, nullptr};
     int side_mode = 1;
     int fork_min_frames = 8;             // batches of at least this many frames run their tile classes on separate streams
     bool small_ct = false;               // plans of a few frames: k_tail_deep as one table-free launch (launch_tail)
@@ -266,10 +263,6 @@ struct pigo_plan {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (side) (void)hipStreamDestroy(side);
-        for (int i = 0; i < 3; ++i) {
-            if (ev_join2[i]) (void)hipEventDestroy(ev_join2[i]);
-            if (side2[i]) (void)hipStreamDestroy(side2[i]);
-        }
     }
     size_t workspace_bytes() const
     {
@@ -568,13 +561,6 @@ bool build_tile_stages(pigo_plan &p)
             begin = i + 1;
         }
     }
-    if (env_int("PIGO_MERGE_STAGES", 0) && ends.size() >= 6 && ends[0] == 0 && ends[1] == 1 && ends[2] == 2 && ends[3] == 3) {
-        // the scan is latency-bound: fuse the single-tree stages after stage 0 pairwise ([1],[2] -> [1..2]; [3],[4..] -> [3..])
-        // and walk their trees with tree-level ILP.  Some windows then evaluate a tree they would have skipped (wasted
-        // work, not a different result: every tree's threshold is still tested in order).
-        ends.erase(ends.begin() + 3);
-        ends.erase(ends.begin() + 1);
-    }
     while ((int)ends.size() > kMaxStages) {  // too many compaction points: merge neighbours that still fit
         std::vector<int> m;
         int b = 0;
@@ -617,7 +603,7 @@ struct TileRule {
 void build_tile_classes(pigo_plan &p)
 {
     std::vector<TileRule> rules;
-    const char *env = getenv("PIGO_TILE_RULES");
+    const char *env = tune_env("PIGO_TILE_RULES");
     std::string spec = env && *env ? env : "6,32,16384;6,16,40960";
     {
         size_t pos = 0;
@@ -686,7 +672,7 @@ void build_tile_classes(pigo_plan &p)
         }
         const size_t nwin = (size_t)(1 << pk.tw_log2) * pk.th;
         const size_t qbytes = 6 * (nwin + nwin / pk.qb_div);
-        pk.dyn += (size_t)(pk.lds ? (p.tab_global ? 0 : p.tab_lds) : p.tab_glb) * 64 * (pk.lds ? 4 : 8) + qbytes + (qbytes >= (size_t)64 * (kLateWaves * kLateTrees + 1) * 4 ? 0 : (size_t)64 * (kLateWaves * kLateTrees + 1) * 4);
+        pk.dyn += (size_t)(pk.lds ? p.tab_lds : p.tab_glb) * 64 * (pk.lds ? 4 : 8) + qbytes + (qbytes >= (size_t)64 * (kLateWaves * kLateTrees + 1) * 4 ? 0 : (size_t)64 * (kLateWaves * kLateTrees + 1) * 4);
         pk.bucket = (int)(sizeof(buckets) / sizeof(buckets[0])) - 1;
         for (int b = 0; b < (int)(sizeof(buckets) / sizeof(buckets[0])); ++b)
             if (pk.dyn <= buckets[b]) {
@@ -737,7 +723,7 @@ bool build_region_groups(pigo_plan &p)
     int nh1 = nh0;
     for (int st = 0; st < a.n_stages; ++st)
         if (a.st_end[st] + 1 == p.nh_reg_mid && p.nh_reg_mid >= a.deep_lo && p.nh_reg_mid <= nh0) nh1 = p.nh_reg_mid;
-    const bool nh1_forced = getenv("PIGO_NH_REG1") != nullptr;
+    const bool nh1_forced = tune_env("PIGO_NH_REG1") != nullptr;
     int nh = nh0;
     // chunk stages: the leading stages that end below the pooling tree
     const int t_pool_wanted = std::max(1, env_int("PIGO_REG_POOL_TREE", 4));
@@ -763,7 +749,7 @@ bool build_region_groups(pigo_plan &p)
     // (experiments: PIGO_REG_CS0 / PIGO_REG_CS1 = "e0,e1,..": the last tree of every chunk stage of the small / mid group; every
     // end must be a stage end of the cascade, at most four, ascending, below the hand-over tree)
     for (int g = 0; g < 2; ++g) {
-        const char *e = getenv(g == 0 ? "PIGO_REG_CS0" : "PIGO_REG_CS1");
+        const char *e = tune_env(g == 0 ? "PIGO_REG_CS0" : "PIGO_REG_CS1");
         if (!e || !*e) continue;
         int v[4], nv = 0;
         for (const char *q = e; *q && nv < 4;) {
@@ -849,7 +835,7 @@ bool build_region_groups(pigo_plan &p)
         const bool no_deep_list = p.max_frames < 8 && env_int("PIGO_REG_DEEP_SMALL", 0) == 0;
         int deep_cap_g = no_deep_list ? 0 : deepg[g];
         const double deep_per_window[NG] = {0.0125, 0.026, 0.026};  // (the 1080p config: 81 k windows -> 1024, 6 k -> the 512 minimum)
-        const bool deep_fixed = getenv(g == 0 ? "PIGO_REG_DEEP0" : g == 1 ? "PIGO_REG_DEEP1" : "PIGO_REG_DEEP2") != nullptr;
+        const bool deep_fixed = tune_env(g == 0 ? "PIGO_REG_DEEP0" : g == 1 ? "PIGO_REG_DEEP1" : "PIGO_REG_DEEP2") != nullptr;
         size_t fixed = 0;
         RegionArgs r{};
         const int halo = up + dn;
@@ -1022,8 +1008,28 @@ pigo_status build_big(pigo_plan &p)
     return PIGO_OK;
 }
 
+// Environment switches.  A handful are for users and always honoured: PIGO_SCAN_VARIANT (force a scan implementation),
+// PIGO_QUEUE_MIN (survivor-queue capacity), PIGO_GRAPH_FRAMES (graph replay of small batches / RunCascade slots),
+// PIGO_COMM_INIT_TIMEOUT_S, PIGO_RCCL_LIB, PIGO_SYNC_DEBUG, PIGO_DEBUG_STATS (debug build).  Everything else is a TUNING switch
+// of the A/B scripts and the parity suite (schedule constants, forced code paths, timing experiments) and is ignored unless
+// PIGO_TUNING=1 is set as well -- a production process cannot wander onto a path nobody benchmarks by inheriting a stray variable.
+bool tuning_enabled()
+{
+    const char *t = getenv("PIGO_TUNING");
+    return t && *t && atoi(t) != 0;
+}
+
+const char *tune_env(const char *name)
+{
+    return tuning_enabled() ? getenv(name) : nullptr;
+}
+
 int env_int(const char *name, int dflt)
 {
+    static const char *const user[] = {"PIGO_SCAN_VARIANT", "PIGO_QUEUE_MIN", "PIGO_GRAPH_FRAMES", "PIGO_COMM_INIT_TIMEOUT_S", "PIGO_SYNC_DEBUG", "PIGO_DEBUG_STATS"};
+    bool is_user = false;
+    for (const char *u : user) is_user = is_user || strcmp(u, name) == 0;
+    if (!is_user && !tuning_enabled()) return dflt;
     const char *v = getenv(name);
     return v && *v ? atoi(v) : dflt;
 }
@@ -1095,7 +1101,6 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     pigo_status st = build_ladder(*p);
     if (st != PIGO_OK) return st;
 
-    p->tab_global = env_int("PIGO_TAB_GLOBAL", 0) != 0;
     p->rot_lds = p->rot && !p->guard && key.dim % 4 == 0 && env_int("PIGO_ROT_LDS", 1) != 0 && env_int("PIGO_LDS_TILES", 1) != 0;
     p->tile_ok = build_tile_stages(*p);
     build_tile_classes(*p);  // also fills ScaleDesc::pitch / up
@@ -1146,21 +1151,13 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         HIP_TRY(hipStreamSynchronize(bs.s));
         const int max_dyn = (160 << 10) - 1024;
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<false, false, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, false, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, true, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        p->tile_threads = env_int("PIGO_TILE_THREADS", 256) == 512 ? 512 : 256;
         p->side_mode = env_int("PIGO_SIDE_STREAM", 1);
         p->fork_min_frames = std::max(1, env_int("PIGO_FORK_MIN_FRAMES", 1));
         p->small_ct = max_frames < 8 && c->d_codes_t.p != nullptr && env_int("PIGO_SMALL_CT", 1) != 0;
-        if (p->side_mode == 2)
-            for (int i = 0; i < 3; ++i) {
-                HIP_TRY(hipStreamCreateWithFlags(&p->side2[i], hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&p->ev_join2[i], hipEventDisableTiming));
-            }
         p->pipe_chunks = std::max(0, std::min(16, env_int("PIGO_PIPE_CHUNKS", 0)));  // 0 = automatic: about 32 frames per chunk
         if (p->pipe_chunks != 1) {
             HIP_TRY(hipStreamCreateWithFlags(&p->tail_stream, hipStreamNonBlocking));  // (a high-priority stream measured no different)
@@ -1325,22 +1322,14 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
         if (cls.ntiles - (v3 ? cls.v3_skip : 0u)) (cls.lds ? has_lds : has_glb) = true;
     // (a small batch is launch-bound: every fork / join costs more than the overlap buys -- one stream then)
     const bool fork = p.side && has_lds && has_glb && !p.profiling && a.nframes >= p.fork_min_frames;
-    const bool fork_all = fork && p.side_mode == 2;
     if (fork) {
         (void)hipEventRecord(p.ev_fork, s);
         (void)hipStreamWaitEvent(p.side, p.ev_fork, 0);
-        if (fork_all)
-            for (int i = 0; i < 3; ++i) (void)hipStreamWaitEvent(p.side2[i], p.ev_fork, 0);
     }
-    int lds_idx = 0;
     for (const pigo_plan::TileClass &cls : p.classes) {
         const uint32_t skip = v3 ? cls.v3_skip : 0u;
         if (cls.ntiles == skip) continue;
         hipStream_t cs = (fork && !cls.lds) ? p.side : s;
-        if (fork_all && cls.lds) {
-            if (lds_idx > 0 && lds_idx <= 3) cs = p.side2[lds_idx - 1];
-            ++lds_idx;
-        }
         ScanArgs ca = a;
         ca.qcap = xcd_cap;
         ca.cls_tile0 = cls.tile0 + skip;
@@ -1352,17 +1341,9 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
         ca.qb_div = cls.qb_div;
         const uint32_t grid = (uint32_t)a.nframes * (cls.ntiles - skip);
         mark(cls.lds ? "scan_tile_lds" : "scan_tile_glb");
-        const bool wide = p.tile_threads == 512;
         if constexpr (!ROT) {
             if (cls.lds) {
-                if (p.tab_global) {
-                    ca.tab_trees = 0;  // no table region in LDS
-                    k_scan_tile<false, false, true, 256, false><<<grid, 256, cls.dyn_lds, cs>>>(ca);
-                } else if (wide) {
-                    k_scan_tile<false, false, true, 512, true><<<grid, 512, cls.dyn_lds, cs>>>(ca);
-                } else {
-                    k_scan_tile<false, false, true, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
-                }
+                k_scan_tile<false, false, true, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
             } else {
                 k_scan_tile<false, false, false, 256, true><<<grid, 256, cls.dyn_lds, cs>>>(ca);
             }
@@ -1376,11 +1357,6 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
     if (fork) {
         (void)hipEventRecord(p.ev_join, p.side);
         (void)hipStreamWaitEvent(s, p.ev_join, 0);
-        if (fork_all)
-            for (int i = 0; i < 3; ++i) {
-                (void)hipEventRecord(p.ev_join2[i], p.side2[i]);
-                (void)hipStreamWaitEvent(s, p.ev_join2[i], 0);
-            }
     }
 }
 

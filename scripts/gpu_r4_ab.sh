@@ -1,6 +1,7 @@
 # A/B loop: bench lines (no side legs) under environment settings:  bash scripts/gpu_r4_ab.sh "NAME:VAR=V VAR2=V2" ...
 # PYTEST_K="expr" runs that part of the GPU parity suite first (PYTEST_ALL=1: all of it); BENCH_ARGS adds bench.py arguments.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export PIGO_TUNING=1  # the settings below are tuning switches (ignored without it)
 mkdir -p gpurun_out/r4
 if [ -n "$PYTEST_ALL" ]; then timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/r4/pytest_all.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r4/pytest_all.log | cut -c1-300; fi
 if [ -n "$PYTEST_K" ]; then timeout 600 python -m pytest tests -m gpu -q -x -k "$PYTEST_K" > gpurun_out/r4/pytest_ab.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r4/pytest_ab.log | cut -c1-300; fi

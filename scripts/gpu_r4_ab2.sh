@@ -1,5 +1,6 @@
 # A/B on two configurations (default batch and the 4K config): bash scripts/gpu_r4_ab2.sh "NAME:ENV=.. ENV2=.." ...
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export PIGO_TUNING=1  # the settings below are tuning switches (ignored without it)
 O=gpurun_out/r4; mkdir -p $O
 C="--no-cpu-baseline --no-gray --shard-frames 0 --no-single-frame"
 show() { python -c "import json,sys; d=json.loads(open('$1').read()); print('$2', d['value'], d['ms_per_step'], d.get('overlap_ms'), d['kernel_ms'], d['cluster_ms'], d.get('verified_frames'))" || tail -3 ${1%.json}.err; }

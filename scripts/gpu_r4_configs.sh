@@ -1,5 +1,6 @@
 # the other bench configurations (noise, rotated, rotated faces, 4K) under environment settings: bash scripts/gpu_r4_configs.sh NAME "ENV=.."
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export PIGO_TUNING=1  # the settings below are tuning switches (ignored without it)
 O=gpurun_out/r4; mkdir -p $O
 name="$1"; envs="$2"
 C="--no-cpu-baseline --no-gray --shard-frames 0 --no-single-frame"

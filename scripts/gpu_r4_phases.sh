@@ -1,5 +1,6 @@
 # phase timers of the small region group (debug build) with and without the side chain next to it
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export PIGO_TUNING=1  # the settings below are tuning switches (ignored without it)
 mkdir -p gpurun_out/r4
 B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-gray --shard-frames 0 --no-single-frame --verify-frames 0 --no-kernel-times"
 for spec in "alone:PIGO_BIG_SKIP=3" "with_side:PIGO_X=1" "with_big_only:PIGO_BIG_SKIP=1" "with_tail_only:PIGO_BIG_SKIP=2" ${EXTRA:-}; do

@@ -1,5 +1,6 @@
 # phase timers of the region groups on a ONE-frame plan (debug build)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export PIGO_TUNING=1  # the settings below are tuning switches (ignored without it)
 python -m pigo_amd.build --debug > /dev/null 2>&1
 B="python bench.py --frames 1 --steps 20 --warmup 2 --no-cpu-baseline --no-gray --shard-frames 0 --no-single-frame --verify-frames 0 --no-kernel-times --variant 3"
 for spec in "g0:PIGO_REG_ONLY=0" "g1:PIGO_REG_ONLY=1" ${EXTRA:-}; do

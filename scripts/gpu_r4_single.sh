@@ -1,5 +1,6 @@
 # Round 4: single 1080p frame (BASELINE config 2 as literally stated) under schedule settings
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export PIGO_TUNING=1  # the settings below are tuning switches (ignored without it)
 O=gpurun_out/r4; mkdir -p $O
 run() { name="$1"; shift; echo -n "$name: "; env "$@" python scripts/single_frame_latency.py 2>&1 | grep "single 1080p" | sed 's/single 1080p frame: //' | cut -c1-200; }
 run default X=1

@@ -1,5 +1,6 @@
 # kernel timeline of single-frame calls: bash scripts/gpu_r4_single_trace.sh NAME "ENV=.."
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export PIGO_TUNING=1  # the settings below are tuning switches (ignored without it)
 mkdir -p gpurun_out/r4
 name="$1"; envs="$2"
 echo -n "$name: "; env $envs python scripts/single_frame_latency.py 2>&1 | grep "single 1080p" | sed 's/single 1080p frame: //' | cut -c1-200

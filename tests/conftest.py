@@ -5,6 +5,10 @@ import sys
 import numpy as np
 import pytest
 
+# the parity suite forces schedule variants, queue sizes and code paths through the library's tuning switches: those are only
+# honoured with PIGO_TUNING=1 (pigo_hip.hip: env_int)
+os.environ.setdefault("PIGO_TUNING", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

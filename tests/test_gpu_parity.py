@@ -738,6 +738,25 @@ def test_sharded_rank_with_a_failing_scan_still_joins_the_collective(pg):
     assert int(wire[:, 0].sum()) > 0
 
 
+def test_tuning_switches_need_pigo_tuning(pg, monkeypatch):
+    """A stray tuning variable in a production environment must not move a plan onto a path nobody benchmarks: without
+    PIGO_TUNING=1 the library ignores PIGO_BIG=0 (k_scan_big still runs); PIGO_SCAN_VARIANT is a user switch and always works."""
+    import torch
+    from pigo_amd import batch
+    monkeypatch.delenv("PIGO_TUNING", raising=False)
+    monkeypatch.setenv("PIGO_BIG", "0")
+    plan = batch.ScanPlan(pg, 1080, 1920, max_frames=8, det_cap=256)
+    assert int(plan.info().variant) == 3
+    d_frames = torch.from_numpy(synth.make_frames("faces", 8, 1080, 1920, seed=3)).cuda()
+    dets, counts = plan.alloc_outputs(8)
+    plan.set_profiling(True)
+    plan.run(d_frames, dets, counts)
+    torch.cuda.synchronize()
+    assert "scan_big" in [k for k, _ in plan.last_timings()]
+    monkeypatch.setenv("PIGO_SCAN_VARIANT", "2")
+    assert int(batch.ScanPlan(pg, 1080, 1920, max_frames=8, det_cap=256).info().variant) == 2
+
+
 def test_comm_abort_and_init_deadline(pg, monkeypatch):
     """pigo_comm_abort (ncclCommAbort) on a real one-rank RCCL communicator: the handle refuses further collectives and can
     still be destroyed; and pigo_comm_init's deadline: a rank whose peer never calls ncclCommInitRank gets PIGO_ERR_HIP back
