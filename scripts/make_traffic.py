@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/rNN_traffic.json from the FETCH_SIZE / WRITE_SIZE (and, optionally, TCC_HIT / TCC_MISS) passes of the round's final script.
 
-    python scripts/make_traffic.py <pmc_fetch.db> <pmc_write.db> <steps in the profiled run> <frames per step> [<pmc_tcc.db>]
+    python scripts/make_traffic.py <pmc_fetch.db> <pmc_write.db> <steps in the profiled run> <frames per step> [<pmc_tcc.db> [<commit>]]
 
 Fabric-side (L2-miss) bytes per frame of the scan kernels = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / frames: FETCH_SIZE is
 doubled per the gfx950 note of MI355X_MICROARCH.md; on this path's byte gathers 2 x FETCH_SIZE equals TCC_MISS_sum x 128 B
@@ -25,12 +25,14 @@ def per_step(db, counter, steps):
 def main():
     fetch_db, write_db, steps, frames = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     tcc_db = sys.argv[5] if len(sys.argv) > 5 else None
+    commit = sys.argv[6] if len(sys.argv) > 6 else None
     f, w = per_step(fetch_db, "FETCH_SIZE", steps), per_step(write_db, "WRITE_SIZE", steps)
     scan = lambda d: sum(v["kib_per_step"] for k, v in d.items() if k.startswith("k_scan") or k.startswith("k_tail"))  # noqa: E731
     fk, wk = scan(f), scan(w)
     rec = {
         "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --frames %d --steps 5 --warmup 2`; "
-                  "scan kernels only (k_scan_region, k_scan_tile*, k_tail_deep*)" % frames,
+                  "scan kernels only (k_scan_region, k_scan_big, k_scan_tile*, k_tail_deep*)" % frames,
+        "commit": commit,
         "frames_per_step": frames, "steps_in_profiled_run": steps,
         "fetch_kib_per_step": round(fk, 1), "write_kib_per_step": round(wk, 1),
         "correction": "FETCH_SIZE doubled (gfx950 rocprofv3 note; upper bound for 4 B/lane copies), WRITE_SIZE as reported",
