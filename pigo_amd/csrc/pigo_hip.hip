@@ -2030,6 +2030,9 @@ extern "C" pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, 
             HIP_TRY(hipHostMalloc((void **)&ns->h_small, 32, hipHostMallocDefault));
             ns->busy = true;
             if (env_int("PIGO_GRAPH_FRAMES", 0) >= 1) {  // capture the call once; without a graph the slot enqueues it every time
+                // (the captured sequence stays on the slot's one stream: a fork onto the plan's side stream inside a capture,
+                // next to plan builds and frees on other threads, crashed once in ~4 runs of the parity suite -- inside the runtime)
+                ns->plan->fork_min_frames = 1 << 30;
                 hipGraph_t graph = nullptr;
                 if (hipStreamBeginCapture(ns->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                     const pigo_status cs = slot_enqueue(*ns);
