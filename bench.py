@@ -636,7 +636,7 @@ def main():
         fps = total_frames / elapsed
         # dominant kernel: the scan.  Variant 2 launches k_scan_tile once per tile class (all classes together
         # read every frame once), variant 1 k_scan_head (+ tail), variant 0 k_scan_mono.
-        scan_names = [k for k in ktimes if k.startswith("scan_") or k.startswith("tail_")]
+        scan_names = [k for k in ktimes if k.startswith(("scan_", "tail_", "big_"))]
         scan_ms = sum(ktimes[k] for k in scan_names)
         dom = {3: "scan_region+scan_tile+tail_deep", 2: "scan_tile+tail_deep", 1: "scan_head+scan_tail", 0: "scan_mono"}.get(int(info.variant), "scan")
         alg_bytes = B * args.rows * args.cols + 16 * ndet  # every frame read once + 16 B per emitted detection

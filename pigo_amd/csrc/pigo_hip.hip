@@ -182,6 +182,8 @@ struct pigo_plan {
     bool big_ok = false;
     BigArgs big{};
     DevBuf<uint2> d_big_items;
+    DevBuf<uint4> d_big_midq;            // k_scan_big -> k_big_pool: [8][big_midcap]
+    uint32_t big_midcap = 0;
     std::vector<uint2> big_items;
     size_t big_lds = 0;
     size_t side_lds = 0;                 // LDS a region workgroup of group 0 leaves to a co-resident side workgroup (0: none reserved)
@@ -266,7 +268,7 @@ struct pigo_plan {
     }
     size_t workspace_bytes() const
     {
-        return d_scales.bytes() + d_tiles.bytes() + d_tiles2.bytes() + d_tabp.bytes() + d_tabr.bytes() + d_tab.bytes() + d_big_items.bytes() + d_queue.bytes() + d_queue2.bytes() +
+        return d_scales.bytes() + d_tiles.bytes() + d_tiles2.bytes() + d_tabp.bytes() + d_tabr.bytes() + d_tab.bytes() + d_big_items.bytes() + d_big_midq.bytes() + d_queue.bytes() + d_queue2.bytes() +
                d_qcount.bytes() + d_raw.bytes() + d_flags.bytes() + d_mq.bytes() + d_ties.bytes() + d_cl_seeds.bytes() + d_cl_nseeds.bytes() + d_cl_tmpn.bytes() + d_cl_tmp.bytes() +
                d_gosort_ws.bytes();
     }
@@ -788,7 +790,7 @@ bool build_region_groups(pigo_plan &p)
     // one small workgroup on the same CU: the first group -- the launch they run next to -- takes that much less (PIGO_REG_RESERVE0_KB,
     // PIGO_REG_RESERVE1_KB for the second group; 0 = the whole CU).
     const bool has_big = p.scales.back().s > env_int("PIGO_REG_S1", 148) && env_int("PIGO_BIG", 1) != 0;
-    const size_t reserve_g[3] = {(size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE0_KB", has_big ? 16 : 0))) << 10,
+    const size_t reserve_g[3] = {(size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE0_KB", has_big ? 8 : 0))) << 10,
                                  (size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE1_KB", 0))) << 10, 0};
     p.side_lds = reserve_g[0];
     const size_t max_dyn_all = (size_t)(160 << 10) - 3072;
@@ -990,7 +992,15 @@ pigo_status build_big(pigo_plan &p)
     }
     if (p.big_items.empty() || p.big_items.size() > (1u << 24)) return PIGO_OK;
     B.cpf = (uint32_t)p.big_items.size();
-    p.big_lds = (size_t)kBigWaves * (kBigChunk * 6 + kBigPool * 16);
+    p.big_lds = (size_t)kBigWaves * (kBigChunk * 6);
+    // k_big_pool's input queues, one per XCD: room for a quarter of the big-scale windows of the frames an XCD scans (8 % survive
+    // the chunk stages on faces, 4 % on noise); an overflow raises the queue flag like every survivor queue
+    {
+        long long bigwin = 0;
+        for (int k = kbig; k < nscales; ++k) bigwin += (long long)p.scales[k].nr * p.scales[k].nc;
+        const long long per_xcd = (bigwin * ((p.max_frames + 7) / 8) + 3) / 4;
+        p.big_midcap = (uint32_t)std::min<long long>(std::max<long long>(4096, per_xcd), 1LL << 28);
+    }
     // the tail of the side chain: ONE k_tail_deep launch without an LDS code table (CT: codes from the node-major pair table in
     // global memory) over all the remaining trees; PIGO_BIG_CT=0: launches with LDS code windows of PIGO_BIG_DEEP_SPLIT trees
     p.big_ct = env_int("PIGO_BIG_CT", 1) != 0 && c.d_codes_t.p != nullptr;
@@ -1211,6 +1221,9 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
                 HIP_TRY(hipMemcpyAsync(p->d_big_items.p, p->big_items.data(), p->big_items.size() * sizeof(uint2), hipMemcpyHostToDevice, bs.s));
                 HIP_TRY(hipStreamSynchronize(bs.s));
                 p->big.items = p->d_big_items.p;
+                HIP_TRY(p->d_big_midq.alloc((size_t)8 * p->big_midcap));
+                p->big.midq = p->d_big_midq.p;
+                p->big.midcap = p->big_midcap;
                 HIP_TRY(hipFuncSetAttribute((const void *)k_scan_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->big_lds));
                 HIP_TRY(hipFuncSetAttribute((const void *)k_scan_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->big_lds));
             }
@@ -1443,10 +1456,14 @@ void launch_big(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry 
     ba.qcap = xcd_cap;
     ba.big = p.big;
     ba.big.next = a.qcount + 40;
+    ba.big.midcount = a.qcount + 48;
+    ba.big.midclaim = a.qcount + 56;
     const int per_cu = std::max(1, env_int("PIGO_BIG_PER_CU", 1));
     const int skip = p.big_skip;
     mark("scan_big");
     if (!(skip & 2)) k_scan_big<ROT><<<256 * per_cu, kBigThreads, p.big_lds, s>>>(ba);
+    mark("big_pool");
+    if (!(skip & 2)) k_big_pool<ROT><<<256 * std::max(1, env_int("PIGO_BIG_POOL_PER_CU", 1)), kBigThreads, 0, s>>>(ba);
     static const char *names[] = {"tail_deep", "tail_deep2", "tail_deep3", "tail_deep4", "tail_deep5", "tail_deep6"};
     const int nl = (int)p.side_splits.size() - 1;
     const uint32_t capq = cap2 / 2;

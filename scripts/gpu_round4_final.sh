@@ -32,6 +32,6 @@ timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST
 python scripts/summarize_prof.py "round 4 final (scripts/gpu_round4_final.sh, commit $COMMIT): $B -- 64 x 1080p SYN-FACES frames per step; 12 scan steps per run (2 warm-up + 5 timed + 5 per-kernel event reps); PIGO_SIDE_STREAM=0 puts the side chain (k_scan_big + k_tail_deep of the big scales) behind the region launches on ONE stream so that every launch is un-overlapped like bench.py's kernel_ms (the timed default runs it NEXT to the first region launch: profiles/r04_overlap_timeline.txt)" $(find $O/trace -name "*.db" | head -1) $(find $O/pmc_fetch -name "*.db" | head -1) $(find $O/pmc_write -name "*.db" | head -1) $(find $O/pmc_tcc -name "*.db" | head -1) $(find $O/pmc_sq -name "*.db" | head -1) $(find $O/pmc_sq2 -name "*.db" | head -1) > $O/final_summary.txt 2>$O/final_summary.err; echo "summary rc=$?"; head -14 $O/final_summary.txt | cut -c1-150
 python scripts/make_traffic.py $(find $O/pmc_fetch -name "*.db" | head -1) $(find $O/pmc_write -name "*.db" | head -1) 12 64 $(find $O/pmc_tcc -name "*.db" | head -1) "$COMMIT" > $O/traffic.json 2>$O/traffic.err; echo "traffic rc=$?"; grep -E "fabric_bytes_per_frame\"|hit_rate" $O/traffic.json
 # region phase timers (debug build): the small group alone and with the side chain next to it
-bash scripts/gpu_r4_phases.sh > $O/region_phases.txt 2>&1; tail -8 $O/region_phases.txt
+python -m pigo_amd.build --debug > /dev/null 2>&1; bash scripts/gpu_r4_phases.sh > $O/region_phases.txt 2>&1; tail -8 $O/region_phases.txt
 rm -rf $O/trace $O/trace_ov $O/pmc_fetch $O/pmc_write $O/pmc_tcc $O/pmc_sq $O/pmc_sq2
 du -sh $O
