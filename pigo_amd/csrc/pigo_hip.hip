@@ -1463,7 +1463,10 @@ void launch_big(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry 
     mark("scan_big");
     if (!(skip & 2)) k_scan_big<ROT><<<256 * per_cu, kBigThreads, p.big_lds, s>>>(ba);
     mark("big_pool");
-    if (!(skip & 2)) k_big_pool<ROT><<<256 * std::max(1, env_int("PIGO_BIG_POOL_PER_CU", 1)), kBigThreads, 0, s>>>(ba);
+    // (two waves per CU: what an XCD's pool waves hold at any time -- 32 CUs x 2 x 64 windows -- is then about one frame's
+    // survivors, the frame the gathers find in the XCD's L2; eight waves per CU hold five frames' worth and miss)
+    const int pool_waves = std::max(1, std::min(kBigWaves, env_int("PIGO_BIG_POOL_WAVES", 1)));
+    if (!(skip & 2)) k_big_pool<ROT><<<256 * std::max(1, env_int("PIGO_BIG_POOL_PER_CU", 1)), 64 * pool_waves, 0, s>>>(ba);
     static const char *names[] = {"tail_deep", "tail_deep2", "tail_deep3", "tail_deep4", "tail_deep5", "tail_deep6"};
     const int nl = (int)p.side_splits.size() - 1;
     const uint32_t capq = cap2 / 2;

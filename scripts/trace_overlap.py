@@ -37,14 +37,14 @@ def main():
     # a step = from one k_scan_region launch pair to k_restore_order
     steps, curstep = [], []
     for n, s, e in rows:
-        if not (n.startswith("k_scan") or n.startswith("k_tail") or n.startswith("k_restore")):
+        if not n.startswith(("k_scan", "k_tail", "k_restore", "k_big")):
             continue
         curstep.append((n, s, e))
         if n == "k_restore_order":
             steps.append(curstep)
             curstep = []
     print(f"# {db}: {len(rows)} dispatches, {len(steps)} scan steps")
-    side = ("k_scan_big", "k_tail_deep", "k_scan_tile")
+    side = ("k_scan_big", "k_big_pool", "k_tail_deep", "k_scan_tile")
     tot = []
     for st in steps:
         t0 = min(s for _, s, _ in st)
