@@ -353,12 +353,17 @@ extern "C" pigo_status pigo_cascade_create(const uint8_t *packet, size_t len, in
         for (int i = 0; i < nt; ++i) lo = std::min(lo, c->thr[i]);
         // Second table: plain 64-tree passes, for plans of a few frames -- there the tail is a handful of entries per wave and
         // the call's latency is the number of dependent passes, not the traffic (one 1080p frame: 0.203 ms vs 0.223 ms).
-        std::vector<int16_t> pe((size_t)nt * 2);
+        // Third table: k_big_pool's steps (lane = window, up to kBigSeg trees of a window in flight): a step that starts at tree t
+        // ends right behind the next tree a window can die at, so no tree is walked that the reference would not have reached.
+        std::vector<int16_t> pe((size_t)nt * 3);
         for (int t = 0; t < nt; ++t) {
             int e = std::min(t + 15, nt - 1);
             while (e < nt - 1 && !(c->thr[e] > lo)) ++e;
             pe[(size_t)t] = (int16_t)std::min(e + 1, t + 64);
             pe[(size_t)nt + t] = (int16_t)std::min(nt, t + 64);
+            int e2 = t;
+            while (e2 < nt - 1 && !(c->thr[e2] > lo)) ++e2;
+            pe[(size_t)2 * nt + t] = (int16_t)std::min(e2 + 1, t + kBigSeg);
         }
         HIP_TRY(c->d_pass_end.alloc(pe.size()));
         HIP_TRY(hipMemcpy(c->d_pass_end.p, pe.data(), pe.size() * 2, hipMemcpyHostToDevice));
@@ -1245,6 +1250,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.codes = c->d_codes.p;
     a.codes_t = c->d_codes_t.p;
     a.pass_end = c->d_pass_end.p + (env_int("PIGO_DEEP_PASS", p->max_frames >= 8 ? 1 : 0) != 0 ? 0 : (size_t)c->ntrees);
+    a.seg_end = c->d_pass_end.p + (size_t)2 * c->ntrees;
     a.late_waves = std::max(1, std::min(kLateWaves, env_int("PIGO_LATE_WAVES", kLateWaves)));
     a.qb_div = 2;  // per class, see build_tile_classes
 #ifdef PIGO_DEBUG_BUILD
@@ -1466,7 +1472,7 @@ void launch_big(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry 
     // (two waves per CU: what an XCD's pool waves hold at any time -- 32 CUs x 2 x 64 windows -- is then about one frame's
     // survivors, the frame the gathers find in the XCD's L2; eight waves per CU hold five frames' worth and miss)
     const int pool_waves = std::max(1, std::min(kBigWaves, env_int("PIGO_BIG_POOL_WAVES", 1)));
-    if (!(skip & 2)) k_big_pool<ROT><<<256 * std::max(1, env_int("PIGO_BIG_POOL_PER_CU", 1)), 64 * pool_waves, 0, s>>>(ba);
+    if (!(skip & 2)) k_big_pool<ROT><<<256 * std::max(1, env_int("PIGO_BIG_POOL_PER_CU", 1)), 64 * std::min(pool_waves, kBigPoolWaves), 0, s>>>(ba);
     static const char *names[] = {"tail_deep", "tail_deep2", "tail_deep3", "tail_deep4", "tail_deep5", "tail_deep6"};
     const int nl = (int)p.side_splits.size() - 1;
     const uint32_t capq = cap2 / 2;
