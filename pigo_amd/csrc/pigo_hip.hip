@@ -968,7 +968,12 @@ pigo_status build_big(pigo_plan &p)
     // hand-over tree: right behind a stage end, as for the tile classes (48 for the facefinder: the next real threshold after 27)
     // (plans of a few frames are latency-bound: a pooled window walks its trees one after the other, 18 dependent round trips to
     // memory per pool step, so there the pool only finishes the cascade's first stages and lane = tree takes over at tree 4)
-    int nh = std::min(env_int("PIGO_NH_BIG", p.max_frames >= 8 ? a.nh_glb : 4), std::min(nt, kTabTrees));
+    // Batches: the pool (lane = window, one wave per CU: its working set has to fit the XCD's L2) takes the windows through the
+    // first real thresholds only and lane = tree takes over at tree 13 -- 2,048 waves with one window each hold a twentieth of the
+    // pool's working set and keep the texture path busy where the pool waits for its dependent round trips (hand-over at
+    // 6 / 13 / 28 / 48: the pool + tail launches take 2.48 / 2.65 / 2.79 / 3.09 ms per 128-frame batch, 6.05 / 6.29 / 6.76 / 7.28 ms
+    // at the 4K config).
+    int nh = std::min(env_int("PIGO_NH_BIG", p.max_frames >= 8 ? 13 : 4), std::min(nt, kTabTrees));
     {
         bool at_end = nh == nt;
         for (int st = 0; st < a.n_stages; ++st) at_end = at_end || a.st_end[st] + 1 == nh;
