@@ -638,23 +638,27 @@ def main():
         # read every frame once), variant 1 k_scan_head (+ tail), variant 0 k_scan_mono.
         scan_names = [k for k in ktimes if k.startswith(("scan_", "tail_", "big_"))]
         scan_ms = sum(ktimes[k] for k in scan_names)
-        dom = {3: "scan_region+scan_tile+tail_deep", 2: "scan_tile+tail_deep", 1: "scan_head+scan_tail", 0: "scan_mono"}.get(int(info.variant), "scan")
+        dom = {3: "scan_region+scan_big+big_pool+tail_deep", 2: "scan_tile+tail_deep", 1: "scan_head+scan_tail", 0: "scan_mono"}.get(int(info.variant), "scan")
         alg_bytes = B * args.rows * args.cols + 16 * ndet  # every frame read once + 16 B per emitted detection
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms else None
         # Memory traffic of the scan kernels: PMC counters cannot be read live; the committed profile of the same workload
         # (separate rocprofv3 --pmc passes, profiles/rNN_traffic.json) gives FABRIC-side bytes per frame -- what the L2s missed,
         # Infinity-Cache hits included -- scaled here to this batch.  It is an upper bound of the HBM bytes.
-        traffic, tnote = None, None
-        tname = {3: "r03_traffic.json", 2: "r01_traffic.json"}.get(int(info.variant))
+        traffic, tnote, tsrc = None, None, None
+        tname = {3: "r04_traffic.json", 2: "r01_traffic.json"}.get(int(info.variant))
         tpath = os.path.join(ROOT, "profiles", tname) if tname else None
-        if tpath and not os.path.exists(tpath) and int(info.variant) == 3:
-            tname = "r02_traffic.json"
-            tpath = os.path.join(ROOT, "profiles", tname)
+        for older in ("r03_traffic.json", "r02_traffic.json"):
+            if tpath and not os.path.exists(tpath) and int(info.variant) == 3:
+                tname = older
+                tpath = os.path.join(ROOT, "profiles", tname)
         if tpath and os.path.exists(tpath) and (args.rows, args.cols, args.kind, args.angle) == (1080, 1920, "faces", 0.0):
             with open(tpath) as fh:
                 trec = json.load(fh)
             traffic = int(trec.get("fabric_bytes_per_frame", trec.get("hbm_bytes_per_frame"))) * B
-            tnote = (f"profiled offline (profiles/{tname}): L2-miss (fabric-side) bytes of the scan kernels = 2 x FETCH_SIZE + WRITE_SIZE per frame, "
+            tsrc = {"file": f"profiles/{tname}", "commit": trec.get("commit"), "frames_per_step_profiled": trec.get("frames_per_step"),
+                    "fabric_bytes_per_frame": int(trec.get("fabric_bytes_per_frame", 0)),
+                    "l2_hit_rate": {k.split("<")[0]: v.get("hit_rate") for k, v in (trec.get("l2_per_step") or {}).items()}}
+            tnote = (f"profiled offline (profiles/{tname}, commit {trec.get('commit')}): L2-miss (fabric-side) bytes of the scan kernels = 2 x FETCH_SIZE + WRITE_SIZE per frame, "
                      "separate rocprofv3 --pmc passes, x frames; FETCH_SIZE x 2 agrees with TCC_MISS_sum x 128 B on these byte gathers; "
                      "includes Infinity-Cache hits (a 128-frame batch is 265 MB), so an upper bound of the HBM bytes")
         out = {
@@ -696,10 +700,12 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                 "traffic": traffic,
                 "traffic_note": tnote,
+                "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "compulsory bytes only (each frame read once + 16 B per detection); the scan is not bound by HBM: the region kernel by its "
-                        "waves' dependent VALU->LDS chains (LDS pipe ~54 % busy, ~44 % of that bank conflicts), the 1 % largest windows by the "
-                        "texture-address rate of 64-line byte gathers -- DESIGN.md section 4",
+                        "LDS pipe (~62 % busy, ~47 % of that bank conflicts of divergent byte gathers), the 1 % largest windows -- gathered from "
+                        "global memory by the side chain that runs NEXT to the region workgroups -- by the L1 fill path (a 128-byte line per "
+                        "gathered byte) -- DESIGN.md section 4",
                 "achieved_over_timed_step": round(alg_bytes / (elapsed / args.steps) / 1e9, 2),
             },
         }

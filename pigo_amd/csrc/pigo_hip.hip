@@ -1179,7 +1179,10 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         p->fork_min_frames = std::max(1, env_int("PIGO_FORK_MIN_FRAMES", 1));
         p->small_ct = max_frames < 8 && c->d_codes_t.p != nullptr && env_int("PIGO_SMALL_CT", 1) != 0;
         p->pipe_chunks = std::max(0, std::min(16, env_int("PIGO_PIPE_CHUNKS", 0)));  // 0 = automatic: about 32 frames per chunk
-        if (p->pipe_chunks != 1) {
+        // (streams are only created where the plan can use them: a process's HIP streams share a handful of hardware queues, and two
+        // of a plan's streams landing on ONE queue silently serialises what was forked -- the one-frame leg of bench.py ran 0.21
+        // instead of 0.17 ms next to a batch plan that held six streams)
+        if (p->pipe_chunks != 1 && max_frames >= 16) {
             HIP_TRY(hipStreamCreateWithFlags(&p->tail_stream, hipStreamNonBlocking));  // (a high-priority stream measured no different)
             for (int i = 0; i < 2; ++i) {
                 HIP_TRY(hipEventCreateWithFlags(&p->ev_tiles[i], hipEventDisableTiming));
@@ -1191,13 +1194,15 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
             HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
         }
-        HIP_TRY(hipStreamCreateWithFlags(&p->grp_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&p->ev_gfork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&p->ev_gjoin, hipEventDisableTiming));
-        HIP_TRY(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+        if (max_frames < 8 && env_int("PIGO_SCAN_VARIANT", -1) == 3) {  // variant 3 forced on a small plan: its region groups side by side
+            HIP_TRY(hipStreamCreateWithFlags(&p->grp_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_gfork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_gjoin, hipEventDisableTiming));
+        }
         // graph replay of small batches: off by default -- on ROCm 7.2 a replayed graph of this sequence is no faster than the
         // eager launches (profiles/r02_experiments.md); PIGO_GRAPH_FRAMES=n turns it on for batches of up to n frames
         p->graph_max_frames = std::max(0, env_int("PIGO_GRAPH_FRAMES", 0));
+        if (p->graph_max_frames > 0) HIP_TRY(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
         p->region_ok = build_region_groups(*p);
         {
             // k_tail_deep's code window starts at the earliest hand-over tree that really occurs: the tile classes' and, with region
