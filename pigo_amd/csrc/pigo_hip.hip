@@ -232,6 +232,7 @@ struct pigo_plan {
     int side_mode = 1;
     int fork_min_frames = 8;             // batches of at least this many frames run their tile classes on separate streams
     bool small_ct = false;               // plans of a few frames: k_tail_deep as one table-free launch (launch_tail)
+    bool split_tail = false;             // plans of a few frames: the global-gather class and the LDS classes each with a queue set and a tail
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t grp_stream = nullptr;    // variant 3, small batches: the second region group runs next to the first
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
@@ -1178,6 +1179,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         p->side_mode = env_int("PIGO_SIDE_STREAM", 1);
         p->fork_min_frames = std::max(1, env_int("PIGO_FORK_MIN_FRAMES", 1));
         p->small_ct = max_frames < 8 && c->d_codes_t.p != nullptr && env_int("PIGO_SMALL_CT", 1) != 0;
+        p->split_tail = max_frames < 8 && env_int("PIGO_SPLIT_TAIL", 1) != 0;
         p->pipe_chunks = std::max(0, std::min(16, env_int("PIGO_PIPE_CHUNKS", 0)));  // 0 = automatic: about 32 frames per chunk
         // (streams are only created where the plan can use them: a process's HIP streams share a handful of hardware queues, and two
         // of a plan's streams landing on ONE queue silently serialises what was forked -- the one-frame leg of bench.py ran 0.21
@@ -1310,10 +1312,10 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
 
 // variant 2, first half of a (chunk of a) batch: one k_scan_tile launch per tile class; `xcd_cap` = entries per XCD queue
 template <bool ROT, bool GUARD, class Mark>
-void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipStream_t s, Mark &mark, bool v3 = false, int what = 3)
+void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipStream_t s, Mark &mark, bool v3 = false, int what = 7)
 {
     // variant 3: the region kernel scans the rungs of its scale groups, k_scan_tile only what lies beyond them
-    // (what & 1: the region launches, what & 2: the tile classes)
+    // (what & 1: the region launches, what & 2: the LDS-pixel tile classes, what & 4: the global-gather tile classes)
 #ifdef PIGO_DEBUG_BUILD
     if (v3 && env_int("PIGO_REG_ONLY", -1) >= 0) what &= 1;
 #endif
@@ -1344,11 +1346,11 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
             (void)hipStreamWaitEvent(s, p.ev_gjoin, 0);
         }
     }
-    if (!(what & 2)) return;
+    if (!(what & 6)) return;
     // fork: classes that gather from global memory go to the side stream when the plan also has LDS-tile classes
     bool has_lds = false, has_glb = false;
     for (const pigo_plan::TileClass &cls : p.classes)
-        if (cls.ntiles - (v3 ? cls.v3_skip : 0u)) (cls.lds ? has_lds : has_glb) = true;
+        if ((what & (cls.lds ? 2 : 4)) && cls.ntiles - (v3 ? cls.v3_skip : 0u)) (cls.lds ? has_lds : has_glb) = true;
     // (a small batch is launch-bound: every fork / join costs more than the overlap buys -- one stream then)
     const bool fork = p.side && has_lds && has_glb && !p.profiling && a.nframes >= p.fork_min_frames;
     if (fork) {
@@ -1357,7 +1359,7 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
     }
     for (const pigo_plan::TileClass &cls : p.classes) {
         const uint32_t skip = v3 ? cls.v3_skip : 0u;
-        if (cls.ntiles == skip) continue;
+        if (cls.ntiles == skip || !(what & (cls.lds ? 2 : 4))) continue;
         hipStream_t cs = (fork && !cls.lds) ? p.side : s;
         ScanArgs ca = a;
         ca.qcap = xcd_cap;
@@ -1552,13 +1554,33 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             if (p.big_ok) {
                 launch_big<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, sa, mark);
             } else {
-                launch_tiles<ROT, GUARD>(p, aa, xcd_cap, sa, mark, true, 2);
+                launch_tiles<ROT, GUARD>(p, aa, xcd_cap, sa, mark, true, 6);
                 launch_tail<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, sa, mark, p.tile_patch);
             }
             if (fork) (void)hipEventRecord(p.ev_join, p.side);
             if (!reg_early) launch_tiles<ROT, GUARD>(p, ab, xcd_cap, s, mark, true, 1);
             launch_tail<ROT, GUARD>(p, ab, xcd_cap, p.d_queue2.p + half2, (uint32_t)half2, s, mark);
             if (fork) (void)hipStreamWaitEvent(s, p.ev_join, 0);
+        } else if (chunks <= 1 && !v3 && p.split_tail && p.side && !p.profiling && a.nframes >= p.fork_min_frames && a.deep_lo < a.ntrees) {
+            // Plans of a few frames (the drop-in single-frame call): two chains side by side, each with its own queue set and its
+            // own tail -- the global-gather class and its tail on the side stream, the LDS classes and theirs on `s`.  The long
+            // entries (face windows: seven dependent passes) come from the big scales of the global class; their tail now runs
+            // while the LDS classes are still scanning instead of behind the last of them.
+            const long long half = qtotal / 2, half2 = p.qcap2 / 2;
+            const uint32_t xcd_cap = (uint32_t)std::min<long long>(half / 8, 0xffffffffLL);
+            ScanArgs aa = a, ab = a;
+            aa.queue = p.d_queue.p;
+            aa.qcount = p.d_qcount.p;
+            ab.queue = p.d_queue.p + half;
+            ab.qcount = p.d_qcount.p + 16;
+            (void)hipEventRecord(p.ev_fork, s);
+            (void)hipStreamWaitEvent(p.side, p.ev_fork, 0);
+            launch_tiles<ROT, GUARD>(p, aa, xcd_cap, p.side, mark, false, 4);
+            launch_tail<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, p.side, mark);
+            (void)hipEventRecord(p.ev_join, p.side);
+            launch_tiles<ROT, GUARD>(p, ab, xcd_cap, s, mark, false, 2);
+            launch_tail<ROT, GUARD>(p, ab, xcd_cap, p.d_queue2.p + half2, (uint32_t)half2, s, mark);
+            (void)hipStreamWaitEvent(s, p.ev_join, 0);
         } else if (chunks <= 1) {
             const uint32_t xcd_cap = (uint32_t)std::min<long long>(qtotal / 8, 0xffffffffLL);
             launch_tiles<ROT, GUARD>(p, a, xcd_cap, s, mark, v3);
