@@ -1519,7 +1519,6 @@ void launch_big(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry 
         mark(names[std::min(i, 5)]);
         if (skip & 1) continue;
         if (p.big_ct && p.big_multi) {  // three windows per wave, lane = (window, tree)
-            ta.tclaim = a.qcount + 32;
             k_tail_multi<ROT, GUARD><<<256 * tail_per_cu, kTmThreads, 0, s>>>(ta);
             continue;
         }
