@@ -188,7 +188,6 @@ struct pigo_plan {
     size_t big_lds = 0;
     size_t side_lds = 0;                 // LDS a region workgroup of group 0 leaves to a co-resident side workgroup (0: none reserved)
     bool big_ct = false;                 // the side chain's k_tail_deep reads its codes from global memory (no LDS table)
-    bool big_multi = false;              // the side chain's tail holds three windows per wave (k_tail_multi)
     bool big_side_first = false;         // PIGO_BIG_FIRST=1: the side chain is launched before the region groups (default: after the first)
     int big_skip = 0;                    // PIGO_BIG_SKIP, timing experiments only (results incomplete): 1 = no tail, 2 = no k_scan_big
     std::vector<int> side_splits;        // code windows of the side chain's k_tail_deep launches: [splits[i], splits[i+1])
@@ -357,8 +356,7 @@ extern "C" pigo_status pigo_cascade_create(const uint8_t *packet, size_t len, in
         // the call's latency is the number of dependent passes, not the traffic (one 1080p frame: 0.203 ms vs 0.223 ms).
         // Third table: k_big_pool's steps (lane = window, up to kBigSeg trees of a window in flight): a step that starts at tree t
         // ends right behind the next tree a window can die at, so no tree is walked that the reference would not have reached.
-        // Fourth table: k_tail_multi's passes (kTmLanes = 21 lanes per window): the last real threshold a pass of 21 trees reaches.
-        std::vector<int16_t> pe((size_t)nt * 4);
+        std::vector<int16_t> pe((size_t)nt * 3);
         for (int t = 0; t < nt; ++t) {
             int e = std::min(t + 15, nt - 1);
             while (e < nt - 1 && !(c->thr[e] > lo)) ++e;
@@ -367,10 +365,6 @@ extern "C" pigo_status pigo_cascade_create(const uint8_t *packet, size_t len, in
             int e2 = t;
             while (e2 < nt - 1 && !(c->thr[e2] > lo)) ++e2;
             pe[(size_t)2 * nt + t] = (int16_t)std::min(e2 + 1, t + kBigSeg);
-            int e3 = -1;  // end of the last segment [.., real threshold] that fits kTmLanes trees from t
-            for (int u = t; u < std::min(nt, t + kTmLanes); ++u)
-                if (c->thr[u] > lo || u == nt - 1) e3 = u + 1;
-            pe[(size_t)3 * nt + t] = (int16_t)(e3 > 0 ? e3 : std::min(nt, t + kTmLanes));
         }
         HIP_TRY(c->d_pass_end.alloc(pe.size()));
         HIP_TRY(hipMemcpy(c->d_pass_end.p, pe.data(), pe.size() * 2, hipMemcpyHostToDevice));
@@ -1021,7 +1015,6 @@ pigo_status build_big(pigo_plan &p)
     // the tail of the side chain: ONE k_tail_deep launch without an LDS code table (CT: codes from the node-major pair table in
     // global memory) over all the remaining trees; PIGO_BIG_CT=0: launches with LDS code windows of PIGO_BIG_DEEP_SPLIT trees
     p.big_ct = env_int("PIGO_BIG_CT", 1) != 0 && c.d_codes_t.p != nullptr;
-    p.big_multi = env_int("PIGO_BIG_MULTI", 1) != 0;
     p.big_side_first = env_int("PIGO_BIG_FIRST", 0) != 0;
     p.big_skip = env_int("PIGO_BIG_SKIP", 0);
     if (nh < nt) {
@@ -1270,7 +1263,6 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     a.codes_t = c->d_codes_t.p;
     a.pass_end = c->d_pass_end.p + (env_int("PIGO_DEEP_PASS", p->max_frames >= 8 ? 1 : 0) != 0 ? 0 : (size_t)c->ntrees);
     a.seg_end = c->d_pass_end.p + (size_t)2 * c->ntrees;
-    a.seg21 = c->d_pass_end.p + (size_t)3 * c->ntrees;
     a.late_waves = std::max(1, std::min(kLateWaves, env_int("PIGO_LATE_WAVES", kLateWaves)));
     a.qb_div = 2;  // per class, see build_tile_classes
 #ifdef PIGO_DEBUG_BUILD
@@ -1518,10 +1510,6 @@ void launch_big(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry 
         const size_t lds = p.big_ct ? 0 : (size_t)(ta.deep_hi - ta.deep_lo) * kCodeStride * 4;
         mark(names[std::min(i, 5)]);
         if (skip & 1) continue;
-        if (p.big_ct && p.big_multi) {  // three windows per wave, lane = (window, tree)
-            k_tail_multi<ROT, GUARD><<<256 * tail_per_cu, kTmThreads, 0, s>>>(ta);
-            continue;
-        }
         if constexpr (ROT) {
             if (p.big_ct) k_tail_deep<true, GUARD, false, true><<<256 * tail_per_cu, threads, lds, s>>>(ta);
             else k_tail_deep<true, GUARD, false><<<256 * tail_per_cu, threads, lds, s>>>(ta);
