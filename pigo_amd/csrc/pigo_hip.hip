@@ -612,7 +612,9 @@ void build_tile_classes(pigo_plan &p)
 {
     std::vector<TileRule> rules;
     const char *env = tune_env("PIGO_TILE_RULES");
-    std::string spec = env && *env ? env : "6,32,16384;6,16,40960";
+    // (plans of a few frames: ONE LDS class -- 64 x 16 tiles for every rung whose footprint fits 40 KiB -- so that the LDS classes
+    // are one launch: a one-frame class is a single round of workgroups, and launches of it run one after the other)
+    std::string spec = env && *env ? env : (p.max_frames < 8 ? "6,16,40960" : "6,32,16384;6,16,40960");
     {
         size_t pos = 0;
         while (pos < spec.size()) {
@@ -691,13 +693,16 @@ void build_tile_classes(pigo_plan &p)
     }
     p.classes.clear();
     p.tiles2.clear();
+    const bool merge_buckets = p.max_frames < 8 && env_int("PIGO_MERGE_BUCKETS", 1) != 0;
     std::vector<char> done(p.scales.size(), 0);
     for (size_t k = 0; k < p.scales.size(); ++k) {
         if (done[k]) continue;
         pigo_plan::TileClass cls{picks[k].tw_log2, picks[k].th, (1 << picks[k].tw_log2) * picks[k].th, picks[k].qb_div, picks[k].lds, (uint32_t)p.tiles2.size(), 0, 0, 0};
         for (size_t j = k; j < p.scales.size(); ++j) {
             const Pick &q = picks[j];
-            if (done[j] || q.tw_log2 != cls.tw_log2 || q.th != cls.th || q.lds != cls.lds || q.bucket != picks[k].bucket || q.qb_div != cls.qb_div) continue;
+            // (plans of a few frames: one launch per tile geometry whatever the LDS footprint -- a one-frame class is a single round
+            // of workgroups bound by a tile's own latency, and two launches of it run one after the other: 25 + 28 us instead of ~30)
+            if (done[j] || q.tw_log2 != cls.tw_log2 || q.th != cls.th || q.lds != cls.lds || (!merge_buckets && q.bucket != picks[k].bucket) || q.qb_div != cls.qb_div) continue;
             done[j] = 1;
             cls.dyn_lds = std::max(cls.dyn_lds, q.dyn);
             const ScaleDesc &sd = p.scales[j];
