@@ -6,7 +6,7 @@ B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-gray --shard-fra
 for spec in "alone:PIGO_BIG_SKIP=3" "with_side:PIGO_X=1" "with_big_only:PIGO_BIG_SKIP=1" "with_tail_only:PIGO_BIG_SKIP=2" ${EXTRA:-}; do
   name="${spec%%:*}"; envs="${spec#*:}"
   echo "== $name"
-  env PIGO_HIP_LIB=$GRAFT_REPO_ROOT/pigo_amd/csrc/libpigo_hip_debug.so PIGO_DEBUG_STATS=1 PIGO_REG_ONLY=0 $envs $B 2>&1 >/dev/null | grep "debug_stats raw" | python -c "
+  env PIGO_HIP_LIB=$GRAFT_REPO_ROOT/pigo_amd/csrc/libpigo_hip_debug.so PIGO_DEBUG_STATS=1 PIGO_REG_ONLY=${REG_ONLY:-0} $envs $B 2>&1 >/dev/null | grep "debug_stats raw" | python -c "
 import sys,ast
 for l in sys.stdin:
     st=ast.literal_eval(l.split('raw:')[1].strip())
