@@ -683,6 +683,50 @@ def test_big_scales_side_chain_and_its_switches(pg, orc, env, monkeypatch):
     assert sum(len(w) for w in want) > 300
 
 
+@pytest.mark.parametrize("angle", [0.0, 0.8])
+@pytest.mark.parametrize("env", [{"PIGO_REG_TAPER0": "0", "PIGO_REG_TAPER1": "0", "PIGO_REG_MERGE_LAUNCH": "0"},
+                                 {"PIGO_REG_TAPER0": "128", "PIGO_REG_TAPER1": "64", "PIGO_REG_MERGE_LAUNCH": "0"},
+                                 {"PIGO_REG_TAPER0": "256", "PIGO_REG_TAPER1": "0", "PIGO_REG_TAPER_MUL": "4", "PIGO_REG_MERGE_LAUNCH": "1"},
+                                 {"PIGO_REG_TAPER0": "64", "PIGO_REG_TAPER1": "64", "PIGO_REG_TAPER_MUL": "1000", "PIGO_REG_MERGE_LAUNCH": "1"},
+                                 {"PIGO_REG_PAR": "1", "PIGO_REG_MERGE_LAUNCH": "0"}])
+def test_region_launch_schedule_switches(pg, orc, env, angle, monkeypatch):
+    """The schedule of the region launches (round 4, second half): the last rungs of a region handed out in smaller chunks
+    (PIGO_REG_TAPER0/1 -- down to every chunk of every rung at the minimum with a huge PIGO_REG_TAPER_MUL), both scale groups in ONE
+    launch (PIGO_REG_MERGE_LAUNCH) or on two streams (PIGO_REG_PAR), each both on and off whatever the library's defaults are.
+    11 frames (8 + 3: the XCD dealing's remainder path inside a merged launch), upright and rotated, every frame against the
+    oracle, raw lists bit-exact.  core/pigo.go:113-191, :212-258."""
+    import threading
+    import torch
+    from pigo_amd import batch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n, rows, cols = 11, 1080, 1920
+    frames = np.concatenate([synth.make_frames("faces", 9, rows, cols, seed=97, rotate_deg=(-79.0 if angle else 0.0)),
+                             synth.make_frames("noise", 2, rows, cols, seed=11)])
+    want = [None] * n
+
+    def work(f):
+        want[f] = orc.run_cascade(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1, angle)
+
+    th = [threading.Thread(target=work, args=(f,)) for f in range(n)]
+    for t in th:
+        t.start()
+    plan = batch.ScanPlan(pg, rows, cols, MinSize=20, MaxSize=1000, ShiftFactor=0.1, ScaleFactor=1.1, angle=angle, max_frames=n, det_cap=1024)
+    assert int(plan.info().variant) == 3
+    d_frames = torch.from_numpy(frames).cuda()
+    dets, counts = plan.alloc_outputs(n)
+    for rep in range(2):
+        plan.run(d_frames, dets, counts)
+    torch.cuda.synchronize()
+    plan.status()
+    for t in th:
+        t.join()
+    got = batch.dets_to_numpy(dets, counts)
+    for f in range(n):
+        assert_same_dets(got[f], want[f], f"region schedule {env} angle {angle} frame {f}", Q_TOL_RAW)
+    assert sum(len(w) for w in want) > (300 if angle == 0.0 else 30)
+
+
 @pytest.mark.parametrize("rccl", [False, True])
 def test_sharded_entry_point_world1_matches_plain_path(pg, orc, rccl):
     """pigo_run_batch_sharded (the C ABI a Go / C++ host shards with) at world size 1: scan + cluster + device-side
