@@ -719,8 +719,9 @@ void build_tile_classes(pigo_plan &p)
 }
 
 // Schedule defaults of the region launches that round 4's second half added (each measured on the GPU before it became a default:
-// profiles/r04_experiments.md section 14; PIGO_REG_TAPER0/1, PIGO_REG_MERGE_LAUNCH override them under PIGO_TUNING=1).
+// profiles/r04_experiments.md section 14; PIGO_REG_TAPER0/1, PIGO_REG_TAPER_MUL0/1, PIGO_REG_MERGE_LAUNCH override them under PIGO_TUNING=1).
 constexpr int kRegTaperMin[2] = {0, 0};  // smallest chunk of the small / mid group's last rungs (0: every chunk is wave_chunk windows)
+constexpr int kRegTaperMul[2] = {2, 2};  // ... from the rung on that starts with fewer than 16 waves x chunk x this many windows left
 constexpr int kRegMergeLaunch = 0;       // both region groups in one launch
 
 // Variant 3: cut the scale ladder into groups by footprint and the image into cells whose region (cell + halo) fits the LDS
@@ -949,7 +950,7 @@ bool build_region_groups(pigo_plan &p)
         r.prio = std::max(0, std::min(3, env_int("PIGO_REG_PRIO", 1)));
         // the last rungs of a region in smaller chunks (k_scan_region: the waves end closer together); 0 = off
         r.taper_min = std::max(0, env_int(g == 0 ? "PIGO_REG_TAPER0" : "PIGO_REG_TAPER1", kRegTaperMin[g > 0 ? 1 : 0]) & ~63);
-        r.taper_mul = std::max(1, env_int("PIGO_REG_TAPER_MUL", 2));
+        r.taper_mul = std::max(1, env_int(g == 0 ? "PIGO_REG_TAPER_MUL0" : "PIGO_REG_TAPER_MUL1", kRegTaperMul[g > 0 ? 1 : 0]));
         r.compress = compress ? 1 : 0;
         r.wave_q = wq;
         for (int j = k_lo; j < k; ++j)
@@ -1343,17 +1344,21 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
         const bool par = p.grp_stream && !p.profiling && (a.nframes < 8 || p.reg_par) && p.regions.size() > 1;
         // both groups in one launch: the second group's workgroups start as the first group's last ones end (per-kernel timing keeps
         // two launches).  The dynamic LDS size is the first group's -- build_region_groups gave the second one the same reserve.
-        if (p.reg_merge && !par && !p.profiling && a.nframes >= 8 && p.regions.size() == 2 && p.regions[1].dyn_lds <= p.regions[0].dyn_lds) {
+        if (p.reg_merge && !par && !p.profiling && a.nframes >= 8 && p.regions.size() == 2) {
             const pigo_plan::RegionGroup &g0 = p.regions[0], &g1 = p.regions[1];
-            const uint32_t n0 = (uint32_t)a.nframes * (uint32_t)(g0.args.ncx * g0.args.ncy), n1 = (uint32_t)a.nframes * (uint32_t)(g1.args.ncx * g1.args.ncy);
-            if (n0 % 8u == 0u) {
+            const size_t dyn = std::max(g0.dyn_lds, g1.dyn_lds);
+            if (dyn + p.side_lds <= (size_t)(160 << 10) - 3072) {  // (the side chain's workgroup still fits next to either group's)
+                // the first group's workgroups padded to a multiple of 8, so that the second group's keep the XCD dealing of a launch
+                // of their own (map_block sends the padding -- frame index >= nframes -- straight home)
+                const uint32_t n0 = ((uint32_t)a.nframes * (uint32_t)(g0.args.ncx * g0.args.ncy) + 7u) & ~7u;
+                const uint32_t n1 = (uint32_t)a.nframes * (uint32_t)(g1.args.ncx * g1.args.ncy);
                 ScanArgs ra = a;
                 ra.qcap = xcd_cap;
                 ra.reg = g0.args;
                 ra.reg2 = g1.args;
                 ra.reg_n0 = n0;
                 mark("scan_region_both");
-                k_scan_region<ROT><<<n0 + n1, kRegThreads, g0.dyn_lds, s>>>(ra);
+                k_scan_region<ROT><<<n0 + n1, kRegThreads, dyn, s>>>(ra);
                 what &= ~1;
             }
         }

@@ -22,6 +22,8 @@ VARIANTS = {
 
 
 def one(name):
+    if name == "debug":  # the debug library (phase timers) of the "all" setting
+        return build.build(force=True, debug=True, defines=["PIGO_OPT_%s=1" % s for s in SWITCHES])
     on = VARIANTS[name]
     defines = ["PIGO_OPT_%s=%d" % (s, on.get(s, 0)) for s in SWITCHES]
     out = os.path.join(build.CSRC, "libpigo_hip_x_%s.so" % name)
@@ -29,7 +31,7 @@ def one(name):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(VARIANTS)
+    names = sys.argv[1:] or list(VARIANTS) + ["debug"]
     with ThreadPoolExecutor(max_workers=8) as ex:
         for path in ex.map(one, names):
             print(path)

@@ -686,12 +686,12 @@ def test_big_scales_side_chain_and_its_switches(pg, orc, env, monkeypatch):
 @pytest.mark.parametrize("angle", [0.0, 0.8])
 @pytest.mark.parametrize("env", [{"PIGO_REG_TAPER0": "0", "PIGO_REG_TAPER1": "0", "PIGO_REG_MERGE_LAUNCH": "0"},
                                  {"PIGO_REG_TAPER0": "128", "PIGO_REG_TAPER1": "64", "PIGO_REG_MERGE_LAUNCH": "0"},
-                                 {"PIGO_REG_TAPER0": "256", "PIGO_REG_TAPER1": "0", "PIGO_REG_TAPER_MUL": "4", "PIGO_REG_MERGE_LAUNCH": "1"},
-                                 {"PIGO_REG_TAPER0": "64", "PIGO_REG_TAPER1": "64", "PIGO_REG_TAPER_MUL": "1000", "PIGO_REG_MERGE_LAUNCH": "1"},
+                                 {"PIGO_REG_TAPER0": "256", "PIGO_REG_TAPER1": "0", "PIGO_REG_TAPER_MUL0": "4", "PIGO_REG_MERGE_LAUNCH": "1"},
+                                 {"PIGO_REG_TAPER0": "64", "PIGO_REG_TAPER1": "64", "PIGO_REG_TAPER_MUL0": "1000", "PIGO_REG_TAPER_MUL1": "1000", "PIGO_REG_MERGE_LAUNCH": "1"},
                                  {"PIGO_REG_PAR": "1", "PIGO_REG_MERGE_LAUNCH": "0"}])
 def test_region_launch_schedule_switches(pg, orc, env, angle, monkeypatch):
     """The schedule of the region launches (round 4, second half): the last rungs of a region handed out in smaller chunks
-    (PIGO_REG_TAPER0/1 -- down to every chunk of every rung at the minimum with a huge PIGO_REG_TAPER_MUL), both scale groups in ONE
+    (PIGO_REG_TAPER0/1 -- down to every chunk of every rung at the minimum with a huge PIGO_REG_TAPER_MUL0/1), both scale groups in ONE
     launch (PIGO_REG_MERGE_LAUNCH) or on two streams (PIGO_REG_PAR), each both on and off whatever the library's defaults are.
     11 frames (8 + 3: the XCD dealing's remainder path inside a merged launch), upright and rotated, every frame against the
     oracle, raw lists bit-exact.  core/pigo.go:113-191, :212-258."""
