@@ -27,6 +27,9 @@ S=(
  "res1_8:PIGO_REG_RESERVE1_KB=8"
  "par:PIGO_REG_PAR=1"
  "par_t01:PIGO_REG_PAR=1 PIGO_REG_TAPER0=128 PIGO_REG_TAPER1=64"
+ "s0_57:PIGO_REG_S0=57"
+ "s1_163:PIGO_REG_S1=163"
+ "s1_135:PIGO_REG_S1=135"
  "def2:"
 )
 PIGO_HIP_LIB=$ALL timeout 600 python scripts/ab_r4b.py "${S[@]}" 2>$O/ab_sched.err | tee $O/ab_sched.txt || tail -3 $O/ab_sched.err
