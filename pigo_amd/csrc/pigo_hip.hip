@@ -235,8 +235,6 @@ struct pigo_plan {
     bool split_tail = false;             // plans of a few frames: the global-gather class and the LDS classes each with a queue set and a tail
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t grp_stream = nullptr;    // variant 3, small batches: the second region group runs next to the first
-    bool reg_merge = false;              // variant 3: both region groups in ONE launch (no drain of the chip between them)
-    bool reg_par = false;                // (experiment) both region groups on their own streams whatever the batch size
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
     // small batches: the launch sequence of pigo_plan_run is captured once per (buffers, batch) and replayed as a hipGraph
     struct GraphCache {
@@ -718,11 +716,9 @@ void build_tile_classes(pigo_plan &p)
     }
 }
 
-// Schedule defaults of the region launches that round 4's second half added (each measured on the GPU before it became a default:
-// profiles/r04_experiments.md section 14; PIGO_REG_TAPER0/1, PIGO_REG_TAPER_MUL0/1, PIGO_REG_MERGE_LAUNCH override them under PIGO_TUNING=1).
-constexpr int kRegTaperMin[2] = {0, 0};  // smallest chunk of the small / mid group's last rungs (0: every chunk is wave_chunk windows)
-constexpr int kRegTaperMul[2] = {2, 2};  // ... from the rung on that starts with fewer than 16 waves x chunk x this many windows left
-constexpr int kRegMergeLaunch = 0;       // both region groups in one launch
+// The quad pass of the region kernel's deep list (k_scan_region), per scale group {small, mid}: PIGO_REG_QUAD0/1 override it under
+// PIGO_TUNING=1 (profiles/r04_experiments.md section 15).
+constexpr int kRegQuad[2] = {0, 0};
 
 // Variant 3: cut the scale ladder into groups by footprint and the image into cells whose region (cell + halo) fits the LDS
 // next to the tables and queues of k_scan_region.  Returns false when the plan is not eligible (rotated scan, stride not a
@@ -809,11 +805,8 @@ bool build_region_groups(pigo_plan &p)
     // one small workgroup on the same CU: the first group -- the launch they run next to -- takes that much less (PIGO_REG_RESERVE0_KB,
     // PIGO_REG_RESERVE1_KB for the second group; 0 = the whole CU).
     const bool has_big = p.scales.back().s > env_int("PIGO_REG_S1", 148) && env_int("PIGO_BIG", 1) != 0;
-    // (one launch for both groups -- p.reg_merge -- has ONE dynamic LDS size: the second group then leaves the same reserve)
-    p.reg_merge = env_int("PIGO_REG_MERGE_LAUNCH", kRegMergeLaunch) != 0;
-    const int reserve0_kb = std::max(0, std::min(96, env_int("PIGO_REG_RESERVE0_KB", has_big ? 8 : 0)));
-    const size_t reserve_g[3] = {(size_t)reserve0_kb << 10,
-                                 (size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE1_KB", p.reg_merge ? reserve0_kb : 0))) << 10, 0};
+    const size_t reserve_g[3] = {(size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE0_KB", has_big ? 8 : 0))) << 10,
+                                 (size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE1_KB", 0))) << 10, 0};
     p.side_lds = reserve_g[0];
     const size_t max_dyn_all = (size_t)(160 << 10) - 3072;
     // (group limits: 51 / 148 measured best after the deep list got cheaper -- 42…51 / 148 within 0.3 %, 62 / 135 3 % slower)
@@ -948,9 +941,14 @@ bool build_region_groups(pigo_plan &p)
         // the 64 x 65 dwords of the first deep pass's codes must fit the wave queues + pools (16.25 KiB)
         r.deep_lds_codes = (env_int("PIGO_REG_DEEP_LDS", 1) != 0 && (size_t)(kRegThreads / 64) * wave_bytes >= (size_t)64 * 65 * 4) ? 1 : 0;
         r.prio = std::max(0, std::min(3, env_int("PIGO_REG_PRIO", 1)));
-        // the last rungs of a region in smaller chunks (k_scan_region: the waves end closer together); 0 = off
-        r.taper_min = std::max(0, env_int(g == 0 ? "PIGO_REG_TAPER0" : "PIGO_REG_TAPER1", kRegTaperMin[g > 0 ? 1 : 0]) & ~63);
-        r.taper_mul = std::max(1, env_int(g == 0 ? "PIGO_REG_TAPER_MUL0" : "PIGO_REG_TAPER_MUL1", kRegTaperMul[g > 0 ? 1 : 0]));
+        // quad pass in front of the deep list's one-window passes (k_scan_region): 16 = four windows x 16 trees, 32 = two x 32.  It needs
+        // the staged codes of 64 + that many trees in the wave queues' LDS and a second list of deep_cap entries in the chunk-stage
+        // tables' (both idle by then); a setting that does not fit falls back to the next smaller one.
+        r.quad = 0;
+        for (int want = env_int(g == 0 ? "PIGO_REG_QUAD0" : "PIGO_REG_QUAD1", kRegQuad[g > 0 ? 1 : 0]); want >= 16 && !r.quad; want -= 16)
+            if ((want == 16 || want == 32) && r.deep_lds_codes && deep_cap_g > 0 && (size_t)(kRegThreads / 64) * wave_bytes >= (size_t)(64 + want) * 65 * 4 &&
+                ((size_t)(k - k_lo) * t_pool * 64 + (size_t)nh * 128) * 4 >= (size_t)deep_cap_g * 8)
+                r.quad = want;
         r.compress = compress ? 1 : 0;
         r.wave_q = wq;
         for (int j = k_lo; j < k; ++j)
@@ -1215,8 +1213,7 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
             HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
         }
-        p->reg_par = env_int("PIGO_REG_PAR", 0) != 0;
-        if ((max_frames < 8 && env_int("PIGO_SCAN_VARIANT", -1) == 3) || p->reg_par) {  // variant 3 forced on a small plan: its region groups side by side
+        if (max_frames < 8 && env_int("PIGO_SCAN_VARIANT", -1) == 3) {  // variant 3 forced on a small plan: its region groups side by side
             HIP_TRY(hipStreamCreateWithFlags(&p->grp_stream, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&p->ev_gfork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&p->ev_gjoin, hipEventDisableTiming));
@@ -1341,28 +1338,7 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
 #endif
     if (v3 && (what & 1)) {
         // a small batch cannot fill the chip with one group's regions: the groups then run next to each other
-        const bool par = p.grp_stream && !p.profiling && (a.nframes < 8 || p.reg_par) && p.regions.size() > 1;
-        // both groups in one launch: the second group's workgroups start as the first group's last ones end (per-kernel timing keeps
-        // two launches).  The dynamic LDS size is the first group's -- build_region_groups gave the second one the same reserve.
-        if (p.reg_merge && !par && !p.profiling && a.nframes >= 8 && p.regions.size() == 2) {
-            const pigo_plan::RegionGroup &g0 = p.regions[0], &g1 = p.regions[1];
-            const size_t dyn = std::max(g0.dyn_lds, g1.dyn_lds);
-            if (dyn + p.side_lds <= (size_t)(160 << 10) - 3072) {  // (the side chain's workgroup still fits next to either group's)
-                // the first group's workgroups padded to a multiple of 8, so that the second group's keep the XCD dealing of a launch
-                // of their own (map_block sends the padding -- frame index >= nframes -- straight home)
-                const uint32_t n0 = ((uint32_t)a.nframes * (uint32_t)(g0.args.ncx * g0.args.ncy) + 7u) & ~7u;
-                const uint32_t n1 = (uint32_t)a.nframes * (uint32_t)(g1.args.ncx * g1.args.ncy);
-                ScanArgs ra = a;
-                ra.qcap = xcd_cap;
-                ra.reg = g0.args;
-                ra.reg2 = g1.args;
-                ra.reg_n0 = n0;
-                mark("scan_region_both");
-                k_scan_region<ROT><<<n0 + n1, kRegThreads, dyn, s>>>(ra);
-                what &= ~1;
-            }
-        }
-        if (what & 1)
+        const bool par = p.grp_stream && !p.profiling && a.nframes < 8 && p.regions.size() > 1;
         for (const pigo_plan::RegionGroup &g : p.regions) {
             const bool first = &g == &p.regions.front();
 #ifdef PIGO_DEBUG_BUILD
@@ -1379,7 +1355,6 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
             ScanArgs ra = a;
             ra.qcap = xcd_cap;
             ra.reg = g.args;
-            ra.reg_n0 = 0;
             mark(first ? "scan_region_small" : &g == &p.regions[1] ? "scan_region_mid" : "scan_region_big");
             k_scan_region<ROT><<<(uint32_t)a.nframes * (uint32_t)(g.args.ncx * g.args.ncy), kRegThreads, g.dyn_lds, gs>>>(ra);
         }

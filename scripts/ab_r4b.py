@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--shift", type=float, default=0.1)
     ap.add_argument("--scale", type=float, default=1.1)
     ap.add_argument("--det-cap", type=int, default=1024)
+    ap.add_argument("--face-rotation", type=float, default=0.0)
     ap.add_argument("--kernel-times", action="store_true")
     ap.add_argument("specs", nargs="+")
     a = ap.parse_args()
@@ -42,7 +43,7 @@ def main():
     from pigo_amd import batch, core, synth
 
     n = a.frames
-    frames = synth.make_frames("faces", n, a.rows, a.cols, seed=1234)
+    frames = synth.make_frames("faces", n, a.rows, a.cols, seed=1234, rotate_deg=a.face_rotation)
     idx = sorted(set([0, 1, n - 2, n - 1]) & set(range(n)))
     orc = oracle.OraclePigo.unpack(synth.facefinder_bytes())
     want, wantc = {}, {}

@@ -11,7 +11,7 @@ from pigo_amd import build  # noqa: E402
 
 SWITCHES = ["DECODE", "LEAFMASK", "L1REG", "COPYX"]
 VARIANTS = {
-    "base": {},                                   # every switch off: round 4's first-half kernel
+    "base": {},                                   # every switch off: round 4's first-half kernel (the library's default is "all" now)
     "all": {s: 1 for s in SWITCHES},
     "dec": {"DECODE": 1},
     "lm": {"DECODE": 1, "LEAFMASK": 1},

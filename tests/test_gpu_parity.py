@@ -684,17 +684,16 @@ def test_big_scales_side_chain_and_its_switches(pg, orc, env, monkeypatch):
 
 
 @pytest.mark.parametrize("angle", [0.0, 0.8])
-@pytest.mark.parametrize("env", [{"PIGO_REG_TAPER0": "0", "PIGO_REG_TAPER1": "0", "PIGO_REG_MERGE_LAUNCH": "0"},
-                                 {"PIGO_REG_TAPER0": "128", "PIGO_REG_TAPER1": "64", "PIGO_REG_MERGE_LAUNCH": "0"},
-                                 {"PIGO_REG_TAPER0": "256", "PIGO_REG_TAPER1": "0", "PIGO_REG_TAPER_MUL0": "4", "PIGO_REG_MERGE_LAUNCH": "1"},
-                                 {"PIGO_REG_TAPER0": "64", "PIGO_REG_TAPER1": "64", "PIGO_REG_TAPER_MUL0": "1000", "PIGO_REG_TAPER_MUL1": "1000", "PIGO_REG_MERGE_LAUNCH": "1"},
-                                 {"PIGO_REG_PAR": "1", "PIGO_REG_MERGE_LAUNCH": "0"}])
-def test_region_launch_schedule_switches(pg, orc, env, angle, monkeypatch):
-    """The schedule of the region launches (round 4, second half): the last rungs of a region handed out in smaller chunks
-    (PIGO_REG_TAPER0/1 -- down to every chunk of every rung at the minimum with a huge PIGO_REG_TAPER_MUL0/1), both scale groups in ONE
-    launch (PIGO_REG_MERGE_LAUNCH) or on two streams (PIGO_REG_PAR), each both on and off whatever the library's defaults are.
-    11 frames (8 + 3: the XCD dealing's remainder path inside a merged launch), upright and rotated, every frame against the
-    oracle, raw lists bit-exact.  core/pigo.go:113-191, :212-258."""
+@pytest.mark.parametrize("env", [{"PIGO_REG_QUAD0": "0", "PIGO_REG_QUAD1": "0"}, {"PIGO_REG_QUAD0": "0", "PIGO_REG_QUAD1": "16"},
+                                 {"PIGO_REG_QUAD0": "32", "PIGO_REG_QUAD1": "16"},
+                                 {"PIGO_REG_QUAD0": "16", "PIGO_REG_QUAD1": "32", "PIGO_NH_REG1": "28", "PIGO_REG_DEEP0": "128", "PIGO_REG_DEEP1": "64"}])
+def test_region_deep_list_quad_pass(pg, orc, env, angle, monkeypatch):
+    """The deep list of k_scan_region with and without its quad pass (four windows x 16 trees or two x 32 per wave, the float32
+    sums running down the segments of lanes, survivors on a second list for the one-window passes): off; 16-tree segments in the
+    mid group only; 32 in the small and 16 in the mid group; 16 in the small group and 32 (or what fits) in the mid group with its
+    hand-over at tree 28 and lists short enough to spill into k_tail_deep -- each whatever the library's defaults are.  11 frames
+    (8 + 3), upright and rotated (faces rotated the way that scan finds them: long deep lists), every frame against the oracle,
+    raw lists bit-exact.  core/pigo.go:113-191, :212-258."""
     import threading
     import torch
     from pigo_amd import batch
@@ -723,7 +722,7 @@ def test_region_launch_schedule_switches(pg, orc, env, angle, monkeypatch):
         t.join()
     got = batch.dets_to_numpy(dets, counts)
     for f in range(n):
-        assert_same_dets(got[f], want[f], f"region schedule {env} angle {angle} frame {f}", Q_TOL_RAW)
+        assert_same_dets(got[f], want[f], f"deep-list quad pass {env} angle {angle} frame {f}", Q_TOL_RAW)
     assert sum(len(w) for w in want) > (300 if angle == 0.0 else 30)
 
 
