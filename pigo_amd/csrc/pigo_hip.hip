@@ -949,9 +949,6 @@ bool build_region_groups(pigo_plan &p)
             if ((want == 16 || want == 32) && r.deep_lds_codes && deep_cap_g > 0 && (size_t)(kRegThreads / 64) * wave_bytes >= (size_t)(64 + want) * 65 * 4 &&
                 ((size_t)(k - k_lo) * t_pool * 64 + (size_t)nh * 128) * 4 >= (size_t)deep_cap_g * 8)
                 r.quad = want;
-        // (the leaves of the quad pass's trees staged behind the second list, 66 dwords per tree, where the tables leave that much)
-        r.quad_leaf = (r.quad && env_int("PIGO_REG_QUAD_LEAF", 1) != 0 &&
-                       ((size_t)(k - k_lo) * t_pool * 64 + (size_t)nh * 128) * 4 >= (size_t)deep_cap_g * 8 + (size_t)r.quad * 66 * 4) ? 1 : 0;
         r.compress = compress ? 1 : 0;
         r.wave_q = wq;
         for (int j = k_lo; j < k; ++j)
