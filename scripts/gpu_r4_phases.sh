@@ -2,8 +2,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export PIGO_TUNING=1  # the settings below are tuning switches (ignored without it)
 mkdir -p gpurun_out/r4
-B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-gray --shard-frames 0 --no-single-frame --verify-frames 0 --no-kernel-times"
-for spec in "alone:PIGO_BIG_SKIP=3" "with_side:PIGO_X=1" "with_big_only:PIGO_BIG_SKIP=1" "with_tail_only:PIGO_BIG_SKIP=2" ${EXTRA:-}; do
+B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-gray --shard-frames 0 --no-single-frame --no-config-legs --verify-frames 0 --no-kernel-times"
+for spec in ${PHASE_SPECS:-alone:PIGO_BIG_SKIP=3 with_side:PIGO_X=1 with_big_only:PIGO_BIG_SKIP=1 with_tail_only:PIGO_BIG_SKIP=2} ${EXTRA:-}; do
   name="${spec%%:*}"; envs="${spec#*:}"
   echo "== $name"
   env PIGO_HIP_LIB=$GRAFT_REPO_ROOT/pigo_amd/csrc/libpigo_hip_debug.so PIGO_DEBUG_STATS=1 PIGO_REG_ONLY=${REG_ONLY:-0} $envs $B 2>&1 >/dev/null | grep "debug_stats raw" | python -c "
