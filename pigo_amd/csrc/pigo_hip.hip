@@ -1209,7 +1209,18 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
             }
         }
         if (p->side_mode) {
-            HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+            // The side stream is a HIGH-PRIORITY stream: the runtime keeps its hardware queues per priority level and hands a new stream
+            // the least used queue of its level, so with a handful of normal-priority streams alive in the process (other plans, the
+            // run slots of pigo_run_cascade, the host's own) a normal-priority side stream can land on the queue of the very stream
+            // it is forked from -- and the side chain then runs BEHIND the region launches instead of next to them, silently (bench.py's
+            // 1,024-frame leg, created after three other plans: 65 ms per step instead of 45).  A queue of the other level cannot
+            // be the caller's.  (PIGO_SIDE_PRIO=0: a normal-priority stream, for the A/B.)
+            int prio_least = 0, prio_greatest = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+            if (env_int("PIGO_SIDE_PRIO", 1) != 0 && prio_greatest != prio_least)
+                HIP_TRY(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_greatest));
+            else
+                HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
         }
