@@ -1214,10 +1214,12 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
             // run slots of pigo_run_cascade, the host's own) a normal-priority side stream can land on the queue of the very stream
             // it is forked from -- and the side chain then runs BEHIND the region launches instead of next to them, silently (bench.py's
             // 1,024-frame leg, created after three other plans: 65 ms per step instead of 45).  A queue of the other level cannot
-            // be the caller's.  (PIGO_SIDE_PRIO=0: a normal-priority stream, for the A/B.)
+            // be the caller's.  Batch plans only: with the side stream of a ONE-frame plan on the other level a call took 0.38 instead of
+            // 0.14 ms (its two fork / join pairs per call cross priority levels, and that is slow) -- there a collision costs 20 %, here
+            // it costs 2.5 x.  (PIGO_SIDE_PRIO=0 / 1: a normal- / high-priority stream whatever the plan, for the A/B.)
             int prio_least = 0, prio_greatest = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-            if (env_int("PIGO_SIDE_PRIO", 1) != 0 && prio_greatest != prio_least)
+            if (env_int("PIGO_SIDE_PRIO", max_frames >= 8 ? 1 : 0) != 0 && prio_greatest != prio_least)
                 HIP_TRY(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_greatest));
             else
                 HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));

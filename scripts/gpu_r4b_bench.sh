@@ -1,0 +1,8 @@
+# bench.py's default line (as the driver runs it) + the single-frame script
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4b; mkdir -p $O
+timeout 600 python bench.py > $O/bench_final.json 2> $O/bench_final.err; echo "bench rc=$?"
+python -c "
+import json;d=json.load(open('$O/bench_final.json'))
+print(d['value'], d['ms_per_step'], d['kernel_ms'], 'cluster', d['cluster_ms'], 'overlap', d['overlap_ms'], 'shard', d['config3_shard']['mwindows_per_s'], 'rot', d['config4_rotated']['upright_faces']['mwindows_per_s'], d['config4_rotated']['rotated_faces']['mwindows_per_s'], '4k', d['config5_4k']['mwindows_per_s'], 'single', d['single_frame']['hbm_resident_ms'], d['single_frame']['host_buffer_ms'], 'ref', d['reference_benchmark']['gpu_ms_per_op'], 'cpu', d['cpu_baseline']['value'])"
+python scripts/single_frame_latency.py 2>&1 | grep "single 1080p" | tee $O/single_frame_final.txt
