@@ -234,6 +234,9 @@ struct pigo_plan {
     bool small_ct = false;               // plans of a few frames: k_tail_deep as one table-free launch (launch_tail)
     bool split_tail = false;             // plans of a few frames: the global-gather class and the LDS classes each with a queue set and a tail
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side_checked = nullptr;  // ensure_side_distinct: the caller's stream `side` has been probed against
+    bool side_checked_valid = false;
+    DevBuf<uint32_t> d_probe;            // {flag, seen} of the probe kernels
     hipStream_t grp_stream = nullptr;    // variant 3, small batches: the second region group runs next to the first
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
     // small batches: the launch sequence of pigo_plan_run is captured once per (buffers, batch) and replayed as a hipGraph
@@ -1661,6 +1664,59 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
     (void)p;
 }
 
+// Plans of a few frames fork their global-gather chain onto p->side twice per call; a NORMAL-priority side stream (the fork / join
+// pairs of such a call are too slow across priority levels, see plan_build) may share its hardware queue with the caller's stream --
+// the runtime hands a new stream the least used of four queues -- and the call then runs its two chains one after the other
+// (0.22 instead of 0.145 ms for a 1080p frame inside bench.py, which holds a dozen streams by then).  So the first call on a
+// caller's stream PROBES the pair (k_probe_wait / k_probe_set: ~20 us when the streams are independent) and, if they are not,
+// creates another side stream while the old one keeps its queue busy, up to six times.  One synchronisation of the caller's
+// stream, once per (plan, caller's stream); never during a stream capture.
+pigo_status ensure_side_distinct(pigo_plan *p, hipStream_t s)
+{
+    if (!p->side || p->max_frames >= 8 || p->profiling || (p->side_checked_valid && p->side_checked == s)) return PIGO_OK;
+    static const bool off = env_int("PIGO_SIDE_PROBE", 1) == 0;
+    if (off) return PIGO_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return PIGO_OK;  // (cannot probe inside a capture; the captured sequences of this library do not fork anyway)
+    }
+    if (!p->d_probe.p) HIP_TRY(p->d_probe.alloc(2));
+    std::vector<hipStream_t> blockers;
+    pigo_status st = PIGO_OK;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        uint32_t seen = 0;
+        hipError_t e = hipMemsetAsync(p->d_probe.p, 0, 8, s);
+        if (e == hipSuccess) e = hipEventRecord(p->ev_fork, s);
+        if (e == hipSuccess) {
+            k_probe_wait<<<1, 64, 0, s>>>(p->d_probe.p, p->d_probe.p + 1, 400000ull);  // ~0.2 ms at most
+            e = hipStreamWaitEvent(p->side, p->ev_fork, 0);
+        }
+        if (e == hipSuccess) {
+            k_probe_set<<<1, 64, 0, p->side>>>(p->d_probe.p);
+            e = hipStreamSynchronize(p->side);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipMemcpy(&seen, p->d_probe.p + 1, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            st = fail(PIGO_ERR_HIP, "side-stream probe: %s", hipGetErrorString(e));
+            break;
+        }
+        if (seen) break;  // the two streams run side by side
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            break;  // keep what we have: slower, not wrong
+        }
+        blockers.push_back(p->side);  // (alive until the search is over: its queue stays the busier one)
+        p->side = fresh;
+    }
+    for (hipStream_t b : blockers) (void)hipStreamDestroy(b);
+    p->side_checked = s;
+    p->side_checked_valid = st == PIGO_OK;
+    return st;
+}
+
 pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame_stride, int nframes, pigo_det *d_dets, int32_t *d_counts,
                              hipStream_t s, int variant)
 {
@@ -1672,6 +1728,7 @@ pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame
     if (p->key.dim % 4 == 0 && (((uintptr_t)d_frames | (uintptr_t)frame_stride) & 3u))  // the tile / patch copies move aligned dwords
         return fail(PIGO_ERR_PARAM, "d_frames and frame_stride must be multiples of 4 bytes when dim is");
     HIP_TRY(hipSetDevice(p->c->device));
+    if (const pigo_status ps = ensure_side_distinct(p, s)) return ps;
     HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nframes * 4, s));
     p->last_nframes = nframes;
     p->n_timed = 0;

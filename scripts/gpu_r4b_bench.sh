@@ -1,6 +1,7 @@
-# bench.py's default line (as the driver runs it) + the single-frame script
+# bench.py's default line (as the driver runs it) + the single-frame script (+ PYTEST_K: a part of the GPU parity suite)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4b; mkdir -p $O
+if [ -n "$PYTEST_K" ]; then timeout 600 python -m pytest tests -m gpu -q -x -k "$PYTEST_K" 2>&1 | tail -2; fi
 timeout 600 python bench.py > $O/bench_final.json 2> $O/bench_final.err; echo "bench rc=$?"
 python -c "
 import json;d=json.load(open('$O/bench_final.json'))
