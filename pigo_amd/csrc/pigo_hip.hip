@@ -1702,6 +1702,8 @@ pigo_status ensure_side_distinct(pigo_plan *p, hipStream_t s)
             st = fail(PIGO_ERR_HIP, "side-stream probe: %s", hipGetErrorString(e));
             break;
         }
+        static const bool dbg = env_int("PIGO_SYNC_DEBUG", 0) != 0;
+        if (dbg) fprintf(stderr, "[pigo] side-stream probe, attempt %d: %s\n", attempt, seen ? "independent" : "same queue");
         if (seen) break;  // the two streams run side by side
         hipStream_t fresh = nullptr;
         if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) {
