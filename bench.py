@@ -481,6 +481,11 @@ def main():
         torch.cuda.synchronize()
         cluster_ms = cev[0].elapsed_time(cev[1]) / reps
 
+    # The timed workload is done: its plan (workspace, streams) goes before the side legs build theirs, so that every leg runs as it
+    # would in a process of its own -- a process's streams share a few hardware queues, and a one-frame plan built next to this
+    # plan's streams measured 0.22-0.26 ms per call against 0.143 alone ("Single frame").
+    del plan
+
     # ---- BASELINE configs[1] as stated: ONE 1080p frame.  (a) resident in HBM, back-to-back launches of the plan;
     # (b) RunCascade on a host buffer: H2D of the frame, scan, D2H of the detections (PCIe-inclusive; never `value`)
     single_leg = None

@@ -3,7 +3,5 @@ export PIGO_TUNING=1
 for spec in "default:PIGO_X=1" "batch_prio0:PIGO_SIDE_PRIO=0" "noprobe:PIGO_SIDE_PROBE=0" "prio0_noprobe:PIGO_SIDE_PRIO=0 PIGO_SIDE_PROBE=0"; do
   name="${spec%%:*}"; envs="${spec#*:}"
   echo "== $name"
-  env $envs PIGO_SYNC_DEBUG=0 timeout 200 python scripts/single_in_process.py 3 2>&1 | grep -v "^\[pigo\] before" | tail -8
+  env $envs timeout 200 python scripts/single_in_process.py 3 2>&1 | grep "one-frame"
 done
-echo "== probe trace (default)"
-env PIGO_SYNC_DEBUG=1 timeout 200 python scripts/single_in_process.py 2 2>&1 | grep -E "probe|one-frame" | head -20
