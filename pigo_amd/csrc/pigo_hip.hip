@@ -1521,7 +1521,9 @@ void launch_big(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, QEntry 
     static const char *names[] = {"tail_deep", "tail_deep2", "tail_deep3", "tail_deep4", "tail_deep5", "tail_deep6"};
     const int nl = (int)p.side_splits.size() - 1;
     const uint32_t capq = cap2 / 2;
-    const int threads = p.side_lds ? 512 : kDeepThreads;
+    // (eight waves: with a region workgroup's 16 x 96 VGPRs on the CU two 64-register waves per SIMD are what is left; fewer waves
+    // make the chain gentler on the region kernel's copy and deep-list phases and slower -- PIGO_BIG_TAIL_THREADS, r04_experiments.md section 17)
+    const int threads = p.side_lds ? std::max(64, std::min(512, env_int("PIGO_BIG_TAIL_THREADS", 512) & ~63)) : kDeepThreads;
     const int tail_per_cu = std::max(1, env_int("PIGO_BIG_TAIL_PER_CU", 1));
     for (int i = 0; i < nl; ++i) {
         ScanArgs ta = a;
