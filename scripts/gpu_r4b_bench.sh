@@ -1,6 +1,7 @@
 # bench.py's default line (as the driver runs it) + the single-frame script (+ PYTEST_K: a part of the GPU parity suite)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4b; mkdir -p $O
+if [ -n "$PYTEST_ALL" ]; then timeout 900 python -m pytest tests -m gpu -q > $O/pytest_final.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $O/pytest_final.log | tail -1 | tee $O/pytest_final_tail.txt; fi
 if [ -n "$PYTEST_K" ]; then timeout 600 python -m pytest tests -m gpu -q -x -k "$PYTEST_K" 2>&1 | tail -2; fi
 timeout 600 python bench.py > $O/bench_final.json 2> $O/bench_final.err; echo "bench rc=$?"
 python -c "

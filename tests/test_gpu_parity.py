@@ -874,6 +874,49 @@ def test_run_cascade_is_reentrant_four_threads_one_handle(orc, graph, monkeypatc
     assert not errors, errors
 
 
+def test_one_frame_plans_in_a_process_full_of_streams(pg, orc):
+    """A process's HIP streams share a handful of hardware queues; plans of a few frames probe their side stream against the
+    caller's on the first call on it and replace it when the two share a queue (ensure_side_distinct).  Twelve live streams
+    and a live batch plan make collisions likely: one-frame plans then run on the default stream and on two of those streams,
+    several times each (first call = probe, later calls = plain), and a fresh handle serves RunCascade -- every result the
+    oracle's.  core/pigo.go:212-258."""
+    import torch
+    from pigo_amd import batch
+    rows, cols = 480, 640
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    frames = synth.make_frames("faces", 8, rows, cols, seed=77)
+    d_frames = torch.from_numpy(frames).cuda()
+    want = [orc.run_cascade(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1, 0.0) for f in range(8)]
+    big = batch.ScanPlan(pg, rows, cols, max_frames=8, det_cap=1024)
+    bd, bc = big.alloc_outputs(8)
+    big.run(d_frames, bd, bc)
+    torch.cuda.synchronize()
+    big.status()
+    got8 = batch.dets_to_numpy(bd, bc)
+    for f in range(8):
+        assert_same_dets(got8[f], want[f], f"batch plan frame {f}", Q_TOL_RAW)
+    plans = [batch.ScanPlan(pg, rows, cols, max_frames=1, det_cap=1024) for _ in range(3)]
+    for k, plan in enumerate(plans):
+        dets, counts = plan.alloc_outputs(1)
+        for st in (None, streams[3 * k + 1], streams[3 * k + 2], None):
+            for rep in range(2):
+                f = (k + rep) % 8
+                if st is None:
+                    plan.run(d_frames[f:f + 1], dets, counts)
+                else:
+                    st.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(st):
+                        plan.run(d_frames[f:f + 1], dets, counts, stream=st)
+                torch.cuda.synchronize()
+                plan.status()
+                assert_same_dets(batch.dets_to_numpy(dets, counts)[0], want[f], f"one-frame plan {k} stream {st} rep {rep}", Q_TOL_RAW)
+    pg2 = core.NewPigo(0).Unpack(synth.facefinder_bytes())
+    for f in range(3):
+        got = pg2.RunCascade(_cp(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1), 0.0)
+        assert_same_dets(got, want[f], f"RunCascade next to {len(streams)} streams, frame {f}", Q_TOL_RAW)
+    assert sum(len(w) for w in want) > 20
+
+
 @pytest.mark.parametrize("runs", [False] + ([True] if __import__("os").environ.get("PIGO_STRESS_FULL") else []))
 def test_slot_capture_next_to_plan_builds_on_other_handles(orc, runs, monkeypatch):
     """Round 2's abort, root cause pinned with rocgdb (gpurun_out/r3/abort_gdb_*.txt): while one thread captures the
