@@ -67,7 +67,9 @@ def parse_args():
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call leg (keeps kernel profiles per-batch)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto, ~15 s)")
     ap.add_argument("--face-rotation", type=float, default=0.0, help="rotate the pasted face patches by this many degrees (-79: what a scan at --angle 0.8 detects)")
-    ap.add_argument("--verify-frames", type=int, default=8, help="frames of the timed batch checked against the CPU oracle afterwards")
+    ap.add_argument("--verify-frames", type=int, default=128,
+                    help="frames of the timed batch checked against the CPU oracle afterwards (default: every frame of the default batch; "
+                         "one host thread per frame, ~0.25 s of one core each)")
     ap.add_argument("--gather", choices=["cabi", "torch"], default="cabi",
                     help="N > 1: all-gather through the C ABI (pigo_run_batch_sharded -> ncclAllGather) or torch.distributed")
     ap.add_argument("--shard-frames", type=int, default=1024,
@@ -689,8 +691,9 @@ def main():
                                + (f"; one all-gather per step via {gather_mode}" if use_dist else ""),
             },
             "verified_frames": verified,
-            "verified_frame_indices": verified_idx,
-            "verification": "the first and the last frames of the timed batch vs the CPU oracle, raw lists and clusters bit-exact (q 0 ulp); counts.max() <= det_cap"
+            "verified_frame_indices": verified_idx if verified < B else f"all {B} frames of the timed batch",
+            "verification": ("EVERY frame" if verified >= B else "the first and the last frames") +
+                            " of the timed batch vs the CPU oracle, raw lists and clusters bit-exact (q 0 ulp); counts.max() <= det_cap"
                             + ("; rank 0's gathered rows vs its lists; one frame of the last rank through the all-gather" if use_dist else ""),
             "gather": gather_mode,
             "kernel_ms_schedule": "per-kernel HIP-event times are taken with the chunked pipeline and the side stream OFF (each launch alone on "
