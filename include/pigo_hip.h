@@ -205,7 +205,8 @@ pigo_status pigo_plan_set_variant(pigo_plan *p, int variant);
  * process's HIP streams share a handful of hardware queues per priority level, so plans for >= 8 frames fork onto a
  * high-priority stream (it cannot share the caller's queue); plans for fewer frames keep a normal-priority side stream and, on
  * the FIRST call with a given `stream`, probe whether the two run side by side -- that first call synchronises `stream` once
- * (never while it is being captured) and may replace the side stream. */
+ * (never while it is being captured) and may replace the side stream.  Only the last probed `stream` is remembered: a host that
+ * alternates two streams on ONE such plan pays the probe on every switch -- give each stream its own plan, as above. */
 pigo_status pigo_plan_run(pigo_plan *p, const uint8_t *d_frames, size_t frame_stride, int nframes, pigo_det *d_dets,
                           int32_t *d_counts, void *stream);
 
