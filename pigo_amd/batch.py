@@ -34,7 +34,7 @@ class ScanPlan:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h and core._lib is not None:
+        if h and core is not None and core._lib is not None:
             core._lib.pigo_plan_destroy(h)
 
     def info(self) -> core.PlanInfo:
@@ -117,6 +117,13 @@ class ScanPlan:
         out = (C.c_uint64 * 16)()
         core.check(self.L.pigo_plan_debug_stats(self._h, out, 16))
         return [int(v) for v in out]
+
+    def debug_trace(self):
+        """Debug build + PIGO_DEBUG_STATS=1: the 16 x 256 trace words of the last run (k_scan_one: per workgroup
+        {start, first item done, all items done, wave 0 leaves} in 10-ns ticks, items, first item, entries taken)."""
+        out = (C.c_uint64 * (16 * 256))()
+        core.check(self.L.pigo_plan_debug_trace(self._h, out, 16 * 256))
+        return np.frombuffer(out, dtype=np.uint64).reshape(256, 16).copy()
 
     def last_queue_count(self):
         n = C.c_int64(0)

@@ -177,6 +177,15 @@ struct pigo_plan {
     };
     std::vector<RegionGroup> regions;
     bool region_ok = false;
+    // plans of a few frames: the whole scan as ONE persistent launch (k_scan_one) -- items, global queues, in-launch consumers
+    bool one_ok = false;
+    OneArgs one{};                       // template (item counts are filled per run: they depend on nframes)
+    BigArgs one_big{};                   // the big rungs' chunk stages as k_scan_one runs them (hand-over at the pooling tree)
+    size_t one_lds = 0;
+    int one_grid = 256;                  // workgroups of the launch: one per CU
+    DevBuf<uint4> d_oneq;                // [8][one.qcap]
+    DevBuf<uint32_t> d_onecnt;           // OneArgs::cnt
+    mutable pigo_det *one_dets = nullptr; // (per run) the caller's detection buffer, for the launch's own order restore
     // variant 3, the rungs beyond the region groups: k_scan_big (persistent, one small workgroup per CU NEXT to a region
     // workgroup) + a chain of k_tail_deep launches whose code windows fit the LDS the region groups leave free
     bool big_ok = false;
@@ -272,7 +281,7 @@ struct pigo_plan {
     }
     size_t workspace_bytes() const
     {
-        return d_scales.bytes() + d_tiles.bytes() + d_tiles2.bytes() + d_tabp.bytes() + d_tabr.bytes() + d_tab.bytes() + d_big_items.bytes() + d_big_midq.bytes() + d_queue.bytes() + d_queue2.bytes() +
+        return d_scales.bytes() + d_tiles.bytes() + d_tiles2.bytes() + d_tabp.bytes() + d_tabr.bytes() + d_tab.bytes() + d_big_items.bytes() + d_big_midq.bytes() + d_oneq.bytes() + d_onecnt.bytes() + d_queue.bytes() + d_queue2.bytes() +
                d_qcount.bytes() + d_raw.bytes() + d_flags.bytes() + d_mq.bytes() + d_ties.bytes() + d_cl_seeds.bytes() + d_cl_nseeds.bytes() + d_cl_tmpn.bytes() + d_cl_tmp.bytes() +
                d_gosort_ws.bytes();
     }
@@ -742,7 +751,7 @@ bool build_region_groups(pigo_plan &p)
     // PIGO_NH_REG1 forces a tree.  It must sit right behind a stage end.
     int nh1 = nh0;
     for (int st = 0; st < a.n_stages; ++st)
-        if (a.st_end[st] + 1 == p.nh_reg_mid && p.nh_reg_mid >= a.deep_lo && p.nh_reg_mid <= nh0) nh1 = p.nh_reg_mid;
+        if (a.st_end[st] + 1 == p.nh_reg_mid && (p.nh_reg_mid >= a.deep_lo || (p.max_frames < 8 && env_int("PIGO_ONE", 1) != 0)) && p.nh_reg_mid <= nh0) nh1 = p.nh_reg_mid;
     const bool nh1_forced = tune_env("PIGO_NH_REG1") != nullptr;
     int nh = nh0;
     // chunk stages: the leading stages that end below the pooling tree
@@ -808,7 +817,8 @@ bool build_region_groups(pigo_plan &p)
     // one small workgroup on the same CU: the first group -- the launch they run next to -- takes that much less (PIGO_REG_RESERVE0_KB,
     // PIGO_REG_RESERVE1_KB for the second group; 0 = the whole CU).
     const bool has_big = p.scales.back().s > env_int("PIGO_REG_S1", 148) && env_int("PIGO_BIG", 1) != 0;
-    const size_t reserve_g[3] = {(size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE0_KB", has_big ? 8 : 0))) << 10,
+    const bool one_mode = p.max_frames < 8 && env_int("PIGO_ONE", 1) != 0;  // k_scan_one: nothing runs next to its workgroups
+    const size_t reserve_g[3] = {(size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE0_KB", (has_big && !one_mode) ? 8 : 0))) << 10,
                                  (size_t)std::max(0, std::min(96, env_int("PIGO_REG_RESERVE1_KB", 0))) << 10, 0};
     p.side_lds = reserve_g[0];
     const size_t max_dyn_all = (size_t)(160 << 10) - 3072;
@@ -817,6 +827,27 @@ bool build_region_groups(pigo_plan &p)
     const int cwmax[NG] = {env_int("PIGO_REG_CW0", 320), env_int("PIGO_REG_CW1", 192), env_int("PIGO_REG_CW2", 128)};
     int k = 0;
     const int nscales = (int)p.scales.size();
+    // k_scan_one (plans of a few frames): how many regions each group gets.  A frame's share of the chip is 256 / max_frames
+    // items; the big rungs take ceil(chunks / 16) of them (one chunk per wave), the groups split the rest by their windows -- a
+    // mid-group window costs about three small-group ones (fixed costs per region, two windows per lane in stage 0).
+    int one_target[NG] = {0, 0, 0};
+    if (one_mode) {
+        long long w[2] = {0, 0}, chunks = 0;
+        for (int j = 0; j < nscales; ++j) {
+            const long long nw = (long long)p.scales[j].nr * p.scales[j].nc;
+            if (p.scales[j].s <= smax[0]) w[0] += nw;
+            else if (p.scales[j].s <= smax[1]) w[1] += nw;
+            else if (has_big) chunks += (nw + kBigChunk - 1) / kBigChunk;
+        }
+        const int slots = std::max(2, env_int("PIGO_ONE_SLOTS", 256) / p.max_frames);
+        const int nbig = (int)std::min<long long>((chunks + kOneBigWaves - 1) / kOneBigWaves, slots / 2);
+        const double cost0 = (double)w[0], cost1 = (double)w[1] * (env_int("PIGO_ONE_W1_X10", 30) / 10.0);
+        const int rest = std::max(2, slots - nbig);
+        int t1 = w[1] > 0 ? std::max(1, (int)(rest * cost1 / std::max(1.0, cost0 + cost1) + 0.5)) : 0;
+        if (w[0] > 0) t1 = std::min(t1, rest - 1);
+        one_target[0] = w[0] > 0 ? std::max(1, rest - t1) : 0;
+        one_target[1] = t1;
+    }
     // (a group that does not fit is fatal for the first two -- the plan then runs variant 2 -- and simply dropped for the third:
     // its rungs stay with the tile classes)
 #define REG_BAIL          \
@@ -852,8 +883,9 @@ bool build_region_groups(pigo_plan &p)
         // waves of that region's workgroup would finish them in three rounds of ~12 dependent passes while the rest of the chip
         // idles -- there every window that passes the hand-over tree goes to k_tail_deep's queue instead, one wave per window
         // over the whole chip: no deep list)
-        const bool no_deep_list = p.max_frames < 8 && env_int("PIGO_REG_DEEP_SMALL", 0) == 0;
-        int deep_cap_g = no_deep_list ? 0 : deepg[g];
+        // (k_scan_one keeps the lists: their quad pass and first passes out of LDS thin what reaches its global queues)
+        const bool no_deep_list = p.max_frames < 8 && !one_mode && env_int("PIGO_REG_DEEP_SMALL", 0) == 0;
+        int deep_cap_g = no_deep_list ? 0 : one_mode ? std::max(64, env_int(g == 0 ? "PIGO_ONE_DEEP0" : "PIGO_ONE_DEEP1", g == 0 ? 512 : 256)) : deepg[g];
         const double deep_per_window[NG] = {0.0125, 0.026, 0.026};  // (the 1080p config: 81 k windows -> 1024, 6 k -> the 512 minimum)
         const bool deep_fixed = tune_env(g == 0 ? "PIGO_REG_DEEP0" : g == 1 ? "PIGO_REG_DEEP1" : "PIGO_REG_DEEP2") != nullptr;
         size_t fixed = 0;
@@ -873,6 +905,40 @@ bool build_region_groups(pigo_plan &p)
         // plan's batch is too small to give every CU a workgroup
         double shrink = 1.0;
         r = RegionArgs{};
+        if (one_target[g] > 0) {
+            // k_scan_one: a frame's items (big bundles + regions of both groups) are about one per CU and frame of the plan -- the
+            // grid with the most regions within the group's share wins (ties: the smaller region)
+            long long best_n = -1, best_bytes = 0;
+            for (int ncx = 1; ncx <= std::max(1, p.key.cols / 16) && ncx <= one_target[g]; ++ncx) {
+                const int cell_w = (((p.key.cols + ncx - 1) / ncx) + 3) & ~3;
+                int pitch = (cell_w + halo + 3 + 3) & ~3;
+                if ((pitch / 4) % 2 == 0) pitch += 4;  // odd dword pitch: consecutive rows start on different banks
+                const int ch_max = (int)(budget / (size_t)pitch) - halo;
+                if (ch_max < 8) continue;
+                const int ncy_min = (p.key.rows + ch_max - 1) / ch_max;
+                const int ncy = std::min(std::max(ncy_min, one_target[g] / ncx), std::max(1, p.key.rows / 8));
+                if (ncy < ncy_min) continue;
+                const int cell_h = (p.key.rows + ncy - 1) / ncy;
+                const long long nreg = (long long)ncx * ncy, bytes = (long long)pitch * (cell_h + halo);
+                const bool within = nreg <= one_target[g], best_within = best_n >= 0 && best_n <= one_target[g];
+                // grids within the share beat grids beyond it; within: more regions, then fewer bytes; beyond: fewer regions
+                bool better = best_n < 0;
+                if (!better && within && !best_within) better = true;
+                if (!better && within && best_within) better = nreg > best_n || (nreg == best_n && bytes < best_bytes);
+                if (!better && !within && !best_within) better = nreg < best_n || (nreg == best_n && bytes < best_bytes);
+                if (better) {
+                    best_n = nreg;
+                    best_bytes = bytes;
+                    r.ncx = ncx;
+                    r.cell_w = cell_w;
+                    r.ncy = ncy;
+                    r.cell_h = cell_h;
+                    r.pitch = pitch;
+                    r.rows = cell_h + halo;
+                }
+            }
+            if (best_n < 0) REG_BAIL;
+        } else
         for (;;) {
             int cw_max = std::max(32, (int)(cwmax[g] * shrink)) & ~3;
             // the widest cells first, then up to six more columns of cells: the grid with the fewest regions wins (ties: the
@@ -943,7 +1009,7 @@ bool build_region_groups(pigo_plan &p)
         r.deep_cap = deep_cap_g;
         // the 64 x 65 dwords of the first deep pass's codes must fit the wave queues + pools (16.25 KiB)
         r.deep_lds_codes = (env_int("PIGO_REG_DEEP_LDS", 1) != 0 && (size_t)(kRegThreads / 64) * wave_bytes >= (size_t)64 * 65 * 4) ? 1 : 0;
-        r.prio = std::max(0, std::min(3, env_int("PIGO_REG_PRIO", 1)));
+        r.prio = one_mode ? 0 : std::max(0, std::min(3, env_int("PIGO_REG_PRIO", 1)));
         // quad pass in front of the deep list's one-window passes (k_scan_region): 16 = four windows x 16 trees, 32 = two x 32.  It needs
         // the staged codes of 64 + that many trees in the wave queues' LDS and a second list of deep_cap entries in the chunk-stage
         // tables' (both idle by then); a setting that does not fit falls back to the next smaller one.
@@ -953,6 +1019,7 @@ bool build_region_groups(pigo_plan &p)
                 ((size_t)(k - k_lo) * t_pool * 64 + (size_t)nh * 128) * 4 >= (size_t)deep_cap_g * 8)
                 r.quad = want;
         r.compress = compress ? 1 : 0;
+        r.one_local = one_mode ? std::max(0, std::min(8, env_int(g == 0 ? "PIGO_ONE_LOCAL0" : "PIGO_ONE_LOCAL1", 1))) : 0;
         r.wave_q = wq;
         for (int j = k_lo; j < k; ++j)
             if (p.scales[j].s >= (1 << 14)) REG_BAIL;
@@ -1047,6 +1114,81 @@ pigo_status build_big(pigo_plan &p)
     if (p.side_lds && p.big_lds + 1536 > p.side_lds) p.side_lds = 0;  // does not fit the reserve: runs, but not next to a region workgroup
     p.big_ok = true;
     return PIGO_OK;
+}
+
+// Plans of a few frames: the whole scan as one persistent launch (k_scan_one).  Needs the region groups (sized for it by
+// build_region_groups: no deep lists, one item per CU and frame), the big rungs' chunk list (build_big) and the node-major code table.
+void build_one(pigo_plan &p)
+{
+    p.one_ok = false;
+    const ScanArgs &a = p.args;
+    const pigo_cascade &c = *p.c;
+    const int nscales = (int)p.scales.size();
+    if (p.max_frames >= 8 || env_int("PIGO_ONE", 1) == 0 || !p.region_ok || p.regions.empty() || p.regions.size() > 2 || p.guard) return;
+    if (!c.d_codes_t.p || c.ntrees > 511 || nscales > 2047) return;  // (tag A of a queue entry: 9 bits of tree, 11 of rung, 3 of frame)
+    const int kbig = p.regions.back().args.k_hi;
+    if (kbig < nscales && !p.big_ok) return;  // rungs beyond the groups that k_scan_big's chunk list does not cover
+    OneArgs &o = p.one;
+    o = OneArgs{};
+    o.ngrp = (int)p.regions.size();
+    o.grp[0] = p.regions[0].args;
+    if (o.ngrp > 1) o.grp[1] = p.regions[1].args;
+    size_t lds = 0;
+    for (const pigo_plan::RegionGroup &g : p.regions) lds = std::max(lds, g.dyn_lds);
+    // the big rungs: chunk stages [0] [1] [2-3] where the cascade's first stages are single trees, else its own leading stages;
+    // lane = tree takes over right behind them
+    p.one_big = BigArgs{};
+    if (kbig < nscales) {
+        BigArgs &B = p.one_big;
+        B = p.big;
+        // ONE chunk stage over the trees [0, 4) where a stage of the cascade ends at tree 3 (all four in flight per window: a
+        // dependent chain of six round trips instead of 24), then [4, 13) five or nine at a time; lane = tree from 13.
+        // (PIGO_ONE_BIG_CS = 3: the stages [0] [1] [2-3] of k_scan_big instead; PIGO_ONE_NH_BIG: the hand-over tree)
+        int n_cs = 0;
+        while (n_cs < a.n_stages && n_cs < 4 && a.st_end[n_cs] < 4) ++n_cs;
+        if (n_cs < 1) return;
+        for (int i = 0; i < 4; ++i) B.cs_end[i] = i < n_cs ? a.st_end[i] : 0;
+        const int want_cs = env_int("PIGO_ONE_BIG_CS", 1);
+        if (want_cs == 1) {
+            B.cs_end[0] = B.cs_end[n_cs - 1];
+            B.cs_end[1] = B.cs_end[2] = B.cs_end[3] = 0;
+            n_cs = 1;
+        } else if (n_cs == 4 && B.cs_end[0] == 0 && B.cs_end[1] == 1 && B.cs_end[2] == 2 && B.cs_end[3] == 3) {
+            B.cs_end[2] = 3;
+            B.cs_end[3] = 0;
+            n_cs = 3;
+        }
+        B.n_cs = n_cs;
+        B.t_pool = B.cs_end[n_cs - 1] + 1;
+        int nh = std::min(env_int("PIGO_ONE_NH_BIG", 13), (int)c.ntrees);
+        {
+            bool at_end = nh == (int)c.ntrees;
+            for (int st = 0; st < a.n_stages; ++st) at_end = at_end || a.st_end[st] + 1 == nh;
+            if (!at_end || nh < B.t_pool) nh = B.t_pool;
+        }
+        B.nh = nh;
+        B.one_pti = env_int("PIGO_ONE_PTI", 9);
+        o.nbig = (B.cpf + kOneBigWaves - 1) / kOneBigWaves;
+        lds = std::max(lds, (size_t)kOneBigWaves * kBigChunk * 6);
+    }
+    p.one_lds = lds;
+    o.nt = std::max(1, std::min(4, env_int("PIGO_ONE_NT", 1)));
+    o.nt_late = std::max(1, std::min(4, env_int("PIGO_ONE_NT_LATE", 4)));
+    o.late_items = std::max(0, env_int("PIGO_ONE_LATE_ITEMS", 8));
+    o.plain_zero = env_int("PIGO_ONE_PLAINZERO", 0);
+    o.restore = (p.det_cap <= kOneRestoreMax && (size_t)p.det_cap * 4 <= lds && env_int("PIGO_ONE_RESTORE", 1) != 0) ? 1 : 0;
+    // queues: room for 1/32 of the windows of the plan's frames in each of the eight (what passes tree 4 of the big rungs, 13 / 28
+    // of the groups: well below 1 % on faces and on noise); an overflow raises the queue flag like every survivor queue
+    o.qcap = (uint32_t)std::min<long long>(std::max<long long>(2048, p.windows * p.max_frames / 32), 1LL << 24);
+    p.one_ok = true;
+    static const bool dbg = env_int("PIGO_SYNC_DEBUG", 0) != 0;
+    if (dbg) {
+        fprintf(stderr, "[pigo] k_scan_one: %u big items (%u chunks; stages end %d, lane = tree from %d)", o.nbig, p.one_big.cpf, p.one_big.t_pool - 1, p.one_big.nh);
+        for (int g = o.ngrp - 1; g >= 0; --g)
+            fprintf(stderr, "; group %d: rungs [%d, %d) %d x %d cells of %d x %d px, region %d x %d, hand-over %d, deep list %d, quad %d", g, o.grp[g].k_lo, o.grp[g].k_hi,
+                    o.grp[g].ncx, o.grp[g].ncy, o.grp[g].cell_w, o.grp[g].cell_h, o.grp[g].pitch, o.grp[g].rows, o.grp[g].nh, o.grp[g].deep_cap, o.grp[g].quad);
+        fprintf(stderr, "; LDS %zu B\n", p.one_lds);
+    }
 }
 
 // Environment switches.  A handful are for users and always honoured: PIGO_SCAN_VARIANT (force a scan implementation),
@@ -1278,6 +1420,17 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
                 HIP_TRY(hipFuncSetAttribute((const void *)k_scan_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->big_lds));
             }
         }
+        build_one(*p);
+        if (p->one_ok) {
+            HIP_TRY(p->d_oneq.alloc((size_t)8 * p->one.qcap));
+            HIP_TRY(p->d_onecnt.alloc(kOneCntWords));
+            HIP_TRY(hipMemsetAsync(p->d_onecnt.p, 0, (size_t)kOneCntWords * 4, bs.s));
+            HIP_TRY(hipMemsetAsync(p->d_oneq.p, 0, (size_t)8 * p->one.qcap * sizeof(uint4), bs.s));  // tags: zero = empty
+            HIP_TRY(hipStreamSynchronize(bs.s));
+            p->one.q = p->d_oneq.p;
+            HIP_TRY(hipFuncSetAttribute((const void *)k_scan_one<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 3072));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_scan_one<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 3072));
+        }
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tail_deep<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
@@ -1328,7 +1481,8 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
     // everything else and as the overflow answer; variant 1 (the first head + tail design) exists in the debug build only
     // variant 3 (LDS regions) for batches; a plan for a handful of frames cannot fill 256 CUs with 1024-thread region workgroups
     // and is served faster by the tile kernel (measured: one 1080p frame 0.20 ms vs 0.29 ms, profiles/r02_experiments.md)
-    p->variant = (c->depth == 6 && c->ntrees > 0 && p->tile_ok) ? env_int("PIGO_SCAN_VARIANT", (p->region_ok && max_frames >= 8) ? 3 : 2) : 0;
+    // ... unless the whole scan fits ONE persistent launch (k_scan_one: variant 3 of such a plan)
+    p->variant = (c->depth == 6 && c->ntrees > 0 && p->tile_ok) ? env_int("PIGO_SCAN_VARIANT", (p->region_ok && (max_frames >= 8 || p->one_ok)) ? 3 : 2) : 0;
     if (p->variant == 3 && !p->region_ok) p->variant = 2;
     if (p->variant == 2 && !p->tile_ok) p->variant = 0;
 #ifdef PIGO_DEBUG_BUILD
@@ -1559,7 +1713,28 @@ template <bool ROT, bool GUARD, class Mark>
 void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t s, Mark &mark)
 {
     const uint32_t nb = (uint32_t)a.nframes * (uint32_t)a.ntiles;
-    if (variant == 2 || variant == 3) {
+    if (variant == 3 && p.one_ok && !GUARD) {
+        // plans of a few frames: ONE persistent launch, at most one workgroup per CU (k_scan_one)
+        OneArgs o = p.one;
+        const uint32_t nf = (uint32_t)a.nframes;
+        o.item_grp1 = o.nbig * nf;
+        o.item_grp0 = o.item_grp1 + (o.ngrp > 1 ? (uint32_t)(o.grp[1].ncx * o.grp[1].ncy) * nf : 0u);
+        o.nitems = o.item_grp0 + (uint32_t)(o.grp[0].ncx * o.grp[0].ncy) * nf;
+        o.cnt = p.d_onecnt.p;
+        ScanArgs oa = a;
+        oa.big = p.one_big;
+        if (o.restore) {
+            // the launch counts its detections itself, its last workgroup restores the reference's order, writes the caller's counts
+            // and leaves the counters zeroed: ONE node on the stream per call (plan_run_variant skips its memsets and k_restore_order)
+            o.dets = p.one_dets;
+            o.counts = a.counts;
+            oa.counts = reinterpret_cast<int32_t *>(p.d_onecnt.p + 26 * kOneLine);
+        } else {
+            (void)hipMemsetAsync(p.d_onecnt.p, 0, (size_t)kOneCntWords * 4, s);
+        }
+        mark("scan_one");
+        k_scan_one<ROT><<<std::min<uint32_t>(o.nitems, (uint32_t)p.one_grid), kRegThreads, p.one_lds, s>>>(oa, o);
+    } else if (variant == 2 || variant == 3) {
         const bool v3 = variant == 3;
         const long long qtotal = p.qcap * (long long)p.max_frames;  // entries of d_queue
         const int want_chunks = p.pipe_chunks > 0 ? p.pipe_chunks : std::max(2, std::min(8, (a.nframes + 31) / 32));
@@ -1732,8 +1907,12 @@ pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame
     if (p->key.dim % 4 == 0 && (((uintptr_t)d_frames | (uintptr_t)frame_stride) & 3u))  // the tile / patch copies move aligned dwords
         return fail(PIGO_ERR_PARAM, "d_frames and frame_stride must be multiples of 4 bytes when dim is");
     HIP_TRY(hipSetDevice(p->c->device));
-    if (const pigo_status ps = ensure_side_distinct(p, s)) return ps;
-    HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nframes * 4, s));
+    if (!(variant == 3 && p->one_ok))
+        if (const pigo_status ps = ensure_side_distinct(p, s)) return ps;
+    // (k_scan_one with its own order restore writes the counts itself)
+    const bool one_restore = variant == 3 && p->one_ok && p->one.restore && !p->guard && !p->scales.empty() && p->c->ntrees != 0;
+    if (!one_restore) HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nframes * 4, s));
+    p->one_dets = d_dets;
     p->last_nframes = nframes;
     p->n_timed = 0;
     if (p->scales.empty() || p->c->ntrees == 0) return PIGO_OK;  // no window is classified / classifyRegion returns 0.0 (pigo.go:146)
@@ -1744,7 +1923,7 @@ pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame
     a.nframes = nframes;
     a.counts = d_counts;
     a.tail_wgs = std::max(8, std::min(256, 2048 / nframes));
-    if (variant >= 1) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)std::max(nframes, 64) * 4, s));
+    if (variant >= 1 && !(variant == 3 && p->one_ok)) HIP_TRY(hipMemsetAsync(p->d_qcount.p, 0, (size_t)std::max(nframes, 64) * 4, s));
 
     size_t ev = 0;
     static const bool sync_debug = env_int("PIGO_SYNC_DEBUG", 0) != 0;  // debugging aid: synchronise and report before every kernel
@@ -1772,8 +1951,8 @@ pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame
     } else {
         launch_scan<false, false>(*p, a, variant, s, mark);
     }
-    mark("restore_order");
-    {
+    if (!one_restore) {
+        mark("restore_order");
         dim3 grid((unsigned)((p->det_cap + kThreads - 1) / kThreads), (unsigned)nframes);
         k_restore_order<<<grid, kThreads, 0, s>>>(p->d_raw.p, d_counts, p->det_cap, d_dets);
     }
@@ -1895,13 +2074,23 @@ extern "C" pigo_status pigo_plan_status(pigo_plan *p)
     int32_t flags[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(flags, p->d_flags.p, 16, hipMemcpyDeviceToHost));
     if (flags[0] || flags[1] || flags[2]) HIP_TRY(hipMemset(p->d_flags.p, 0, 16));
+    uint32_t rep[12] = {0};
+    if ((flags[0] & 16) && p->one_ok) HIP_TRY(hipMemcpy(rep, p->d_onecnt.p + kOneReport, sizeof rep, hipMemcpyDeviceToHost));
+    if (flags[0] && p->one_ok) {  // k_scan_one: a run that overflowed a queue or gave up a hand-off may have left entries and counters behind
+        HIP_TRY(hipMemset(p->d_onecnt.p, 0, (size_t)kOneCntWords * 4));
+        HIP_TRY(hipMemset(p->d_oneq.p, 0, (size_t)8 * p->one.qcap * sizeof(uint4)));
+    }
     p->last_flags[0] = flags[0];
     p->last_flags[1] = flags[1];
     p->last_flags[2] = flags[2];
     if (flags[1]) return fail(PIGO_ERR_PANIC, "the reference would panic: pixel index out of range in classifyRotatedRegion (pigo.go:167-179)");
+    if ((flags[0] & 16) && p->one_ok)
+        return fail(PIGO_ERR_CAPACITY,
+                    "hand-off timeout inside k_scan_one (queue %u slot %u, workgroup %u: done at claim %u, now %u / %u of %u items; alloc %u / %u, head %u; tags %08x %08x)",
+                    rep[0], rep[1], rep[11], rep[2], rep[3], rep[4], rep[8], rep[5], rep[6], rep[7], rep[9], rep[10]);
     if (flags[0])
-        return fail(PIGO_ERR_CAPACITY, "survivor queue overflow (%s%s%s%s)", (flags[0] & 1) ? "tile LDS queue " : "", (flags[0] & 2) ? "survivor queue " : "",
-                    (flags[0] & 4) ? "second-level tail queue " : "", (flags[0] & 8) ? "bucket list" : "");
+        return fail(PIGO_ERR_CAPACITY, "survivor queue overflow (%s%s%s%s%s)", (flags[0] & 1) ? "tile LDS queue " : "", (flags[0] & 2) ? "survivor queue " : "",
+                    (flags[0] & 4) ? "second-level tail queue " : "", (flags[0] & 8) ? "bucket list " : "", (flags[0] & 16) ? "hand-off timeout inside k_scan_one" : "");
     if (flags[2]) return fail(PIGO_ERR_CAPACITY, "a frame has more than det_cap (%d) detections: its list is truncated (d_counts holds the true count)", p->det_cap);
     return PIGO_OK;
 }
@@ -1993,6 +2182,12 @@ extern "C" pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n)
     *n = 0;
     if (p->last_nframes == 0) return PIGO_OK;
     HIP_TRY(hipMemcpy(h.data(), p->d_qcount.p, (size_t)p->last_nframes * 4, hipMemcpyDeviceToHost));
+    if (p->variant == 3 && p->one_ok) {  // k_scan_one: the eight queues' `alloc` counters
+        std::vector<uint32_t> hc(8 * kOneLine);
+        HIP_TRY(hipMemcpy(hc.data(), p->d_onecnt.p, hc.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t x = 0; x < 8; ++x) *n += hc[x * kOneLine];
+        return PIGO_OK;
+    }
     if (p->variant >= 2) {
         uint32_t h8[8] = {0};
         HIP_TRY(hipMemcpy(h8, p->d_qcount.p, sizeof h8, hipMemcpyDeviceToHost));

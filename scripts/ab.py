@@ -2,7 +2,7 @@
 ClusterDetections per step), every setting checked against the CPU oracle on the first two and the last two frames of the batch
 (raw lists and clusters, bit-exact) -- the frames and the oracle's answers are made once per process.
 
-    PIGO_HIP_LIB=pigo_amd/csrc/libpigo_hip_x_all.so python scripts/ab_r4b.py "name:VAR=V VAR2=V" "other:VAR=W" ...
+    PIGO_HIP_LIB=pigo_amd/csrc/libpigo_hip_x_all.so python scripts/ab.py "name:VAR=V VAR2=V" "other:VAR=W" ...
 
 A spec's variables are set (under PIGO_TUNING=1) while its plan is built -- the library reads its tuning switches at plan creation --
 and removed afterwards.  Optional arguments before the specs: --frames N --steps K --reps R --angle A --kernel-times.
@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--det-cap", type=int, default=1024)
     ap.add_argument("--face-rotation", type=float, default=0.0)
     ap.add_argument("--kernel-times", action="store_true")
+    ap.add_argument("--no-cluster", action="store_true", help="the step is RunCascade alone (bench.py's single_frame leg)")
+    ap.add_argument("--kind", default="faces")
     ap.add_argument("specs", nargs="+")
     a = ap.parse_args()
     os.environ["PIGO_TUNING"] = "1"
@@ -43,7 +45,7 @@ def main():
     from pigo_amd import batch, core, synth
 
     n = a.frames
-    frames = synth.make_frames("faces", n, a.rows, a.cols, seed=1234, rotate_deg=a.face_rotation)
+    frames = synth.make_frames(a.kind, n, a.rows, a.cols, seed=1234, rotate_deg=a.face_rotation)
     idx = sorted(set([0, 1, n - 2, n - 1]) & set(range(n)))
     orc = oracle.OraclePigo.unpack(synth.facefinder_bytes())
     want, wantc = {}, {}
@@ -87,7 +89,8 @@ def main():
 
         def step():
             plan.run(d_frames, dets, counts)
-            plan.cluster(dets, counts, 0.2, out=cl)
+            if not a.no_cluster:
+                plan.cluster(dets, counts, 0.2, out=cl)
 
         for _ in range(3):
             step()
@@ -105,7 +108,7 @@ def main():
         gcl = batch.dets_to_numpy(cl[1], cl[2])
         bad = None
         for f in idx:
-            bad = bad or same(got[f], want[f]) or same(gcl[f], wantc[f])
+            bad = bad or same(got[f], want[f]) or (None if a.no_cluster else same(gcl[f], wantc[f]))
         kt = ""
         if a.kernel_times:
             plan.set_profiling(True)
