@@ -16,9 +16,10 @@ configs[1] (1920x1080, facefinder, MinSize 20, MaxSize 1000, ShiftFactor 0.1, Sc
 batch of `--frames` seeded SYN-FACES frames per GPU (weak scaling: per-GPU work is fixed as N grows).
 
 Rank 0 prints ONE JSON line (see the task contract) with two extra objects:
-  roofline      HBM roofline of the dominant kernel (k_scan_head): algorithmic bytes per launch (every frame
-                read once + 16 B per detection) / that kernel's mean duration measured with HIP events on the
-                launch stream; peak 8.0 TB/s.
+  roofline      HBM roofline of the scan (k_scan_region's two launches with the big scales' side chain k_scan_big ->
+                k_big_pool -> k_tail_deep running next to them): algorithmic bytes per step (every frame read once +
+                16 B per detection) / the timed step; the per-kernel HIP-event times (each launch alone on the launch
+                stream) are in kernel_ms; peak 8.0 TB/s.
   single_frame  BASELINE configs[1] taken literally: one 1080p frame per call, HBM-resident and from a host buffer.
   puploc        side measurement of the RunDetector kernel (4096 requests x 63 perturbations): requests/s.
   gray          side measurement of the RgbToGrayscale kernel (the streaming step in front of the scan): GB/s vs 8 TB/s.
@@ -58,7 +59,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--det-cap", type=int, default=1024)
     ap.add_argument("--gather-cap", type=int, default=64)
-    ap.add_argument("--variant", type=int, default=None, help="0 = monolithic, 1 = head+queue+tail, 2 = LDS tile (default)")
+    ap.add_argument("--variant", type=int, default=None, help="0 = monolithic, 2 = LDS tiles, 3 = LDS regions + big-scale side chain / k_scan_one (default: the plan's choice, 3)")
     ap.add_argument("--no-cluster", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -483,28 +484,39 @@ def main():
         torch.cuda.synchronize()
         cluster_ms = cev[0].elapsed_time(cev[1]) / reps
 
-    # The timed workload is done: its plan (workspace, streams) goes before the side legs build theirs, so that every leg runs as it
-    # would in a process of its own -- a process's streams share a few hardware queues, and a one-frame plan built next to this
-    # plan's streams measured 0.22-0.26 ms per call against 0.143 alone ("Single frame").
-    del plan
-
-    # ---- BASELINE configs[1] as stated: ONE 1080p frame.  (a) resident in HBM, back-to-back launches of the plan;
-    # (b) RunCascade on a host buffer: H2D of the frame, scan, D2H of the detections (PCIe-inclusive; never `value`)
+    # ---- BASELINE configs[1] as stated: ONE 1080p frame.  (a) resident in HBM, back-to-back launches of a one-frame plan (ONE
+    # kernel launch per call: k_scan_one) -- first NEXT TO the live batch plan of the timed workload (its workspace and streams still
+    # there: until round 4 a one-frame call forked onto a side stream of its own and ran 0.22-0.26 ms in that company against 0.145
+    # alone), then alone; (b) RunCascade on a host buffer: H2D of the frame, scan, results written to pinned host memory by the scan
+    # itself (PCIe-inclusive; never `value`)
     single_leg = None
     side_legs = rank == 0 and n_gpus == 1 and not args.no_gray
+    one_next_ms = None
     if side_legs and not args.no_single_frame:
         plan1 = batch.ScanPlan(pg, args.rows, args.cols, MinSize=args.min_size, MaxSize=args.max_size, ShiftFactor=args.shift,
                                ScaleFactor=args.scale, angle=args.angle, max_frames=1, det_cap=args.det_cap)
         d1, c1 = plan1.alloc_outputs(1)
-        for _ in range(5):
-            plan1.run(d_frames[:1], d1, c1)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(100):
-            plan1.run(d_frames[:1], d1, c1)
-        torch.cuda.synchronize()
-        dev_ms = (time.perf_counter() - t1) / 100 * 1e3
-        plan1.status()
+
+        def time_one(n=100):
+            for _ in range(5):
+                plan1.run(d_frames[:1], d1, c1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                plan1.run(d_frames[:1], d1, c1)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t1) / n * 1e3
+            plan1.status()
+            return ms
+
+        one_next_ms = time_one()
+        # (the one-frame plan's list for frame 0 is the batch plan's, record for record)
+        if int(c1[0].item()) != int(counts[0].item()) or not torch.equal(d1[0, :int(c1[0].item())], dets[0, :int(counts[0].item())]):
+            raise SystemExit("bench.py: VERIFICATION FAILED: the one-frame plan's detections for frame 0 differ from the batch plan's")
+    # The timed workload's plan (workspace, streams) goes before the other side legs build theirs: every leg as in a process of its own.
+    del plan
+    if side_legs and not args.no_single_frame:
+        dev_ms = time_one()
         cp1 = core.CascadeParams(MinSize=args.min_size, MaxSize=args.max_size, ShiftFactor=args.shift, ScaleFactor=args.scale,
                                  ImageParams=core.ImageParams(Pixels=frames[0], Rows=args.rows, Cols=args.cols, Dim=args.cols))
         for _ in range(3):
@@ -515,8 +527,11 @@ def main():
         host_ms = (time.perf_counter() - t1) / 20 * 1e3
         w1 = int(info.windows_per_frame)
         single_leg = {"hbm_resident_ms": round(dev_ms, 4), "hbm_resident_mwindows_per_s": round(w1 / dev_ms / 1e3, 1),
+                      "hbm_resident_next_to_live_batch_plan_ms": round(one_next_ms, 4),
                       "host_buffer_ms": round(host_ms, 4), "host_buffer_mwindows_per_s": round(w1 / host_ms / 1e3, 1),
-                      "note": "one frame per call; host_buffer includes PCIe H2D/D2H and two synchronisations"}
+                      "launches_per_call": 1,
+                      "note": "one frame per call, ONE kernel launch (k_scan_one); frame 0's list checked against the batch plan's; "
+                              "host_buffer includes PCIe H2D, the results written to pinned host memory by the launch, and one synchronisation"}
         del plan1
 
     # ---- side measurement, outside the timed region: RgbToGrayscale (core/grayscale.go:8-23), the streaming step in
@@ -705,8 +720,12 @@ def main():
             "overlap_ms": round(sum(v for k, v in ktimes.items() if k != "end") + (cluster_ms or 0.0) - elapsed / args.steps * 1e3, 4),
             "roofline": {
                 "bound": "hbm", "kernel": "k_" + dom, "kernel_ms_per_batch": round(scan_ms, 4),
-                "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+                # achieved / frac: algorithmic bytes of a step / the TIMED step (the launches of a step overlap -- the big scales' side
+                # chain runs next to the region launches --, so the serial sum of the per-kernel times is not a duration of anything;
+                # it stays below as achieved_over_serial_kernel_sum)
+                "achieved": round(alg_bytes / (elapsed / args.steps) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
+                "achieved_over_serial_kernel_sum": round(achieved, 2) if achieved else None,
                 "traffic": traffic,
                 "traffic_note": tnote,
                 "traffic_source": tsrc,
@@ -715,7 +734,6 @@ def main():
                         "LDS pipe (~62 % busy, ~47 % of that bank conflicts of divergent byte gathers), the 1 % largest windows -- gathered from "
                         "global memory by the side chain that runs NEXT to the region workgroups -- by the L1 fill path (a 128-byte line per "
                         "gathered byte) -- DESIGN.md section 4",
-                "achieved_over_timed_step": round(alg_bytes / (elapsed / args.steps) / 1e9, 2),
             },
         }
         out["config3_shard"] = shard_leg

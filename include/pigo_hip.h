@@ -201,12 +201,10 @@ pigo_status pigo_plan_set_variant(pigo_plan *p, int variant);
  * Nothing is synchronised; call pigo_plan_status() after synchronising the stream.  A plan owns ONE
  * workspace: enqueue all work of a plan on the same stream (or order the streams yourself); use one
  * plan per stream for concurrent batches.
- * Internal streams: a plan forks part of its work onto a side stream of its own and joins it before this call returns.  A
- * process's HIP streams share a handful of hardware queues per priority level, so plans for >= 8 frames fork onto a
- * high-priority stream (it cannot share the caller's queue); plans for fewer frames keep a normal-priority side stream and, on
- * the FIRST call with a given `stream`, probe whether the two run side by side -- that first call synchronises `stream` once
- * (never while it is being captured) and may replace the side stream.  Only the last probed `stream` is remembered: a host that
- * alternates two streams on ONE such plan pays the probe on every switch -- give each stream its own plan, as above. */
+ * Internal streams: a plan for >= 8 frames forks part of its work onto a high-priority side stream of its own (it cannot
+ * share the caller's hardware queue) and joins it before this call returns.  A plan for fewer frames is ONE kernel launch on
+ * `stream` (k_scan_one: the scan, the hand-over to the deep trees and the order restore inside one persistent grid) -- no side
+ * stream, no fork / join, nothing synchronised or probed. */
 pigo_status pigo_plan_run(pigo_plan *p, const uint8_t *d_frames, size_t frame_stride, int nframes, pigo_det *d_dets,
                           int32_t *d_counts, void *stream);
 

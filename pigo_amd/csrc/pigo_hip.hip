@@ -186,6 +186,7 @@ struct pigo_plan {
     DevBuf<uint4> d_oneq;                // [8][one.qcap]
     DevBuf<uint32_t> d_onecnt;           // OneArgs::cnt
     mutable pigo_det *one_dets = nullptr; // (per run) the caller's detection buffer, for the launch's own order restore
+    int32_t *one_host_flags = nullptr;   // (per run, pigo_run_cascade's slots) OneArgs::host_flags
     // variant 3, the rungs beyond the region groups: k_scan_big (persistent, one small workgroup per CU NEXT to a region
     // workgroup) + a chain of k_tail_deep launches whose code windows fit the LDS the region groups leave free
     bool big_ok = false;
@@ -241,11 +242,9 @@ struct pigo_plan {
     int side_mode = 1;
     int fork_min_frames = 8;             // batches of at least this many frames run their tile classes on separate streams
     bool small_ct = false;               // plans of a few frames: k_tail_deep as one table-free launch (launch_tail)
+    bool no_fork = false;                // (while pigo_plan_run captures a graph) every launch stays on the one stream
     bool split_tail = false;             // plans of a few frames: the global-gather class and the LDS classes each with a queue set and a tail
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t side_checked = nullptr;  // ensure_side_distinct: the caller's stream `side` has been probed against
-    bool side_checked_valid = false;
-    DevBuf<uint32_t> d_probe;            // {flag, seen} of the probe kernels
     hipStream_t grp_stream = nullptr;    // variant 3, small batches: the second region group runs next to the first
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
     // small batches: the launch sequence of pigo_plan_run is captured once per (buffers, batch) and replayed as a hipGraph
@@ -852,6 +851,7 @@ bool build_region_groups(pigo_plan &p)
     // its rungs stay with the tile classes)
 #define REG_BAIL          \
     {                     \
+        if (env_int("PIGO_SYNC_DEBUG", 0) != 0) fprintf(stderr, "[pigo] region group %d does not fit (pigo_hip.hip:%d)\n", g, __LINE__); \
         if (g < 2) return false; \
         k = k_lo;         \
         dropped = true;   \
@@ -909,10 +909,11 @@ bool build_region_groups(pigo_plan &p)
             // k_scan_one: a frame's items (big bundles + regions of both groups) are about one per CU and frame of the plan -- the
             // grid with the most regions within the group's share wins (ties: the smaller region)
             long long best_n = -1, best_bytes = 0;
-            for (int ncx = 1; ncx <= std::max(1, p.key.cols / 16) && ncx <= one_target[g]; ++ncx) {
+            for (int ncx = 1; ncx <= std::max(1, p.key.cols / 16); ++ncx) {  // (beyond the share too: wide cells may not fit the packed offsets)
                 const int cell_w = (((p.key.cols + ncx - 1) / ncx) + 3) & ~3;
                 int pitch = (cell_w + halo + 3 + 3) & ~3;
                 if ((pitch / 4) % 2 == 0) pitch += 4;  // odd dword pitch: consecutive rows start on different banks
+                if ((long long)std::max(up, dn) * pitch + std::max(up, dn) > 32767) continue;  // packed int16 offsets (checked again below)
                 const int ch_max = (int)(budget / (size_t)pitch) - halo;
                 if (ch_max < 8) continue;
                 const int ncy_min = (p.key.rows + ch_max - 1) / ch_max;
@@ -1124,10 +1125,16 @@ void build_one(pigo_plan &p)
     const ScanArgs &a = p.args;
     const pigo_cascade &c = *p.c;
     const int nscales = (int)p.scales.size();
-    if (p.max_frames >= 8 || env_int("PIGO_ONE", 1) == 0 || !p.region_ok || p.regions.empty() || p.regions.size() > 2 || p.guard) return;
-    if (!c.d_codes_t.p || c.ntrees > 511 || nscales > 2047) return;  // (tag A of a queue entry: 9 bits of tree, 11 of rung, 3 of frame)
+    static const bool dbg = env_int("PIGO_SYNC_DEBUG", 0) != 0;
+    auto why = [&](const char *reason) {
+        if (dbg && p.max_frames < 8) fprintf(stderr, "[pigo] k_scan_one not used for this plan: %s\n", reason);
+    };
+    if (p.max_frames >= 8 || env_int("PIGO_ONE", 1) == 0) return;
+    if (!p.region_ok || p.regions.empty() || p.regions.size() > 2) return why("no region groups (or more than two)");
+    if (p.guard) return why("a frame shape whose rotated scan may panic (guard kernels)");
+    if (!c.d_codes_t.p || c.ntrees > 511 || nscales > 2047) return why("cascade / ladder beyond the queue entry's fields");  // (tag A of a queue entry: 9 bits of tree, 11 of rung, 3 of frame)
     const int kbig = p.regions.back().args.k_hi;
-    if (kbig < nscales && !p.big_ok) return;  // rungs beyond the groups that k_scan_big's chunk list does not cover
+    if (kbig < nscales && !p.big_ok) return why("rungs beyond the region groups without a chunk list");  // rungs beyond the groups that k_scan_big's chunk list does not cover
     OneArgs &o = p.one;
     o = OneArgs{};
     o.ngrp = (int)p.regions.size();
@@ -1146,7 +1153,7 @@ void build_one(pigo_plan &p)
         // (PIGO_ONE_BIG_CS = 3: the stages [0] [1] [2-3] of k_scan_big instead; PIGO_ONE_NH_BIG: the hand-over tree)
         int n_cs = 0;
         while (n_cs < a.n_stages && n_cs < 4 && a.st_end[n_cs] < 4) ++n_cs;
-        if (n_cs < 1) return;
+        if (n_cs < 1) return why("no single-tree stage in front of the cascade");
         for (int i = 0; i < 4; ++i) B.cs_end[i] = i < n_cs ? a.st_end[i] : 0;
         const int want_cs = env_int("PIGO_ONE_BIG_CS", 1);
         if (want_cs == 1) {
@@ -1180,8 +1187,8 @@ void build_one(pigo_plan &p)
     // queues: room for 1/32 of the windows of the plan's frames in each of the eight (what passes tree 4 of the big rungs, 13 / 28
     // of the groups: well below 1 % on faces and on noise); an overflow raises the queue flag like every survivor queue
     o.qcap = (uint32_t)std::min<long long>(std::max<long long>(2048, p.windows * p.max_frames / 32), 1LL << 24);
+    if (const int forced = env_int("PIGO_ONE_QCAP", 0); forced > 0) o.qcap = (uint32_t)forced;  // (tests: a queue that overflows)
     p.one_ok = true;
-    static const bool dbg = env_int("PIGO_SYNC_DEBUG", 0) != 0;
     if (dbg) {
         fprintf(stderr, "[pigo] k_scan_one: %u big items (%u chunks; stages end %d, lane = tree from %d)", o.nbig, p.one_big.cpf, p.one_big.t_pool - 1, p.one_big.nh);
         for (int g = o.ngrp - 1; g >= 0; --g)
@@ -1339,7 +1346,9 @@ pigo_status plan_build(pigo_cascade *c, const PlanKey &key, int max_frames, int 
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(hipFuncSetAttribute((const void *)k_scan_tile<true, true, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         p->side_mode = env_int("PIGO_SIDE_STREAM", 1);
-        p->fork_min_frames = std::max(1, env_int("PIGO_FORK_MIN_FRAMES", 1));
+        // (a batch plan's side stream is a high-priority one, and a fork / join pair across priority levels costs ~0.24 ms: small
+        // batches on such a plan stay on the caller's stream)
+        p->fork_min_frames = std::max(1, env_int("PIGO_FORK_MIN_FRAMES", max_frames >= 8 ? 8 : 1));
         p->small_ct = max_frames < 8 && c->d_codes_t.p != nullptr && env_int("PIGO_SMALL_CT", 1) != 0;
         p->split_tail = max_frames < 8 && env_int("PIGO_SPLIT_TAIL", 1) != 0;
         p->pipe_chunks = std::max(0, std::min(16, env_int("PIGO_PIPE_CHUNKS", 0)));  // 0 = automatic: about 32 frames per chunk
@@ -1539,7 +1548,7 @@ void launch_tiles(const pigo_plan &p, const ScanArgs &a, uint32_t xcd_cap, hipSt
     for (const pigo_plan::TileClass &cls : p.classes)
         if ((what & (cls.lds ? 2 : 4)) && cls.ntiles - (v3 ? cls.v3_skip : 0u)) (cls.lds ? has_lds : has_glb) = true;
     // (a small batch is launch-bound: every fork / join costs more than the overlap buys -- one stream then)
-    const bool fork = p.side && has_lds && has_glb && !p.profiling && a.nframes >= p.fork_min_frames;
+    const bool fork = p.side && has_lds && has_glb && !p.profiling && !p.no_fork && a.nframes >= p.fork_min_frames;
     if (fork) {
         (void)hipEventRecord(p.ev_fork, s);
         (void)hipStreamWaitEvent(p.side, p.ev_fork, 0);
@@ -1728,6 +1737,7 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             // and leaves the counters zeroed: ONE node on the stream per call (plan_run_variant skips its memsets and k_restore_order)
             o.dets = p.one_dets;
             o.counts = a.counts;
+            o.host_flags = p.one_host_flags;
             oa.counts = reinterpret_cast<int32_t *>(p.d_onecnt.p + 26 * kOneLine);
         } else {
             (void)hipMemsetAsync(p.d_onecnt.p, 0, (size_t)kOneCntWords * 4, s);
@@ -1746,7 +1756,7 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             const long long half = qtotal / 2, half2 = p.qcap2 / 2;
             const uint32_t xcd_cap = (uint32_t)std::min<long long>(half / 8, 0xffffffffLL);
             // (per-kernel timing runs the same launches one after the other on `s`)
-            const bool fork = p.side && !p.profiling;
+            const bool fork = p.side && !p.profiling && !p.no_fork;
             hipStream_t sa = fork ? p.side : s;
             if (fork) {
                 (void)hipEventRecord(p.ev_fork, s);
@@ -1771,7 +1781,7 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             if (!reg_early) launch_tiles<ROT, GUARD>(p, ab, xcd_cap, s, mark, true, 1);
             launch_tail<ROT, GUARD>(p, ab, xcd_cap, p.d_queue2.p + half2, (uint32_t)half2, s, mark);
             if (fork) (void)hipStreamWaitEvent(s, p.ev_join, 0);
-        } else if (chunks <= 1 && !v3 && p.split_tail && p.side && !p.profiling && a.nframes >= p.fork_min_frames && a.deep_lo < a.ntrees) {
+        } else if (chunks <= 1 && !v3 && p.split_tail && p.side && !p.profiling && !p.no_fork && a.nframes >= p.fork_min_frames && a.deep_lo < a.ntrees) {
             // Plans of a few frames (the drop-in single-frame call): two chains side by side, each with its own queue set and its
             // own tail -- the global-gather class and its tail on the side stream, the LDS classes and theirs on `s`.  The long
             // entries (face windows: seven dependent passes) come from the big scales of the global class; their tail now runs
@@ -1841,61 +1851,6 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
     (void)p;
 }
 
-// Plans of a few frames fork their global-gather chain onto p->side twice per call; a NORMAL-priority side stream (the fork / join
-// pairs of such a call are too slow across priority levels, see plan_build) may share its hardware queue with the caller's stream --
-// the runtime hands a new stream the least used of four queues -- and the call then runs its two chains one after the other
-// (0.22 instead of 0.145 ms for a 1080p frame inside bench.py, which holds a dozen streams by then).  So the first call on a
-// caller's stream PROBES the pair (k_probe_wait / k_probe_set: ~20 us when the streams are independent) and, if they are not,
-// creates another side stream while the old one keeps its queue busy, up to six times.  One synchronisation of the caller's
-// stream, once per (plan, caller's stream); never during a stream capture.
-pigo_status ensure_side_distinct(pigo_plan *p, hipStream_t s)
-{
-    if (!p->side || p->max_frames >= 8 || p->profiling || (p->side_checked_valid && p->side_checked == s)) return PIGO_OK;
-    static const bool off = env_int("PIGO_SIDE_PROBE", 1) == 0;
-    if (off) return PIGO_OK;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return PIGO_OK;  // (cannot probe inside a capture; the captured sequences of this library do not fork anyway)
-    }
-    if (!p->d_probe.p) HIP_TRY(p->d_probe.alloc(2));
-    std::vector<hipStream_t> blockers;
-    pigo_status st = PIGO_OK;
-    for (int attempt = 0; attempt < 6; ++attempt) {
-        uint32_t seen = 0;
-        hipError_t e = hipMemsetAsync(p->d_probe.p, 0, 8, s);
-        if (e == hipSuccess) e = hipEventRecord(p->ev_fork, s);
-        if (e == hipSuccess) {
-            k_probe_wait<<<1, 64, 0, s>>>(p->d_probe.p, p->d_probe.p + 1, 400000ull);  // ~0.2 ms at most
-            e = hipStreamWaitEvent(p->side, p->ev_fork, 0);
-        }
-        if (e == hipSuccess) {
-            k_probe_set<<<1, 64, 0, p->side>>>(p->d_probe.p);
-            e = hipStreamSynchronize(p->side);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e == hipSuccess) e = hipMemcpy(&seen, p->d_probe.p + 1, 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            st = fail(PIGO_ERR_HIP, "side-stream probe: %s", hipGetErrorString(e));
-            break;
-        }
-        static const bool dbg = env_int("PIGO_SYNC_DEBUG", 0) != 0;
-        if (dbg) fprintf(stderr, "[pigo] side-stream probe, attempt %d: %s\n", attempt, seen ? "independent" : "same queue");
-        if (seen) break;  // the two streams run side by side
-        hipStream_t fresh = nullptr;
-        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) {
-            (void)hipGetLastError();
-            break;  // keep what we have: slower, not wrong
-        }
-        blockers.push_back(p->side);  // (alive until the search is over: its queue stays the busier one)
-        p->side = fresh;
-    }
-    for (hipStream_t b : blockers) (void)hipStreamDestroy(b);
-    p->side_checked = s;
-    p->side_checked_valid = st == PIGO_OK;
-    return st;
-}
-
 pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame_stride, int nframes, pigo_det *d_dets, int32_t *d_counts,
                              hipStream_t s, int variant)
 {
@@ -1907,8 +1862,6 @@ pigo_status plan_run_variant(pigo_plan *p, const uint8_t *d_frames, size_t frame
     if (p->key.dim % 4 == 0 && (((uintptr_t)d_frames | (uintptr_t)frame_stride) & 3u))  // the tile / patch copies move aligned dwords
         return fail(PIGO_ERR_PARAM, "d_frames and frame_stride must be multiples of 4 bytes when dim is");
     HIP_TRY(hipSetDevice(p->c->device));
-    if (!(variant == 3 && p->one_ok))
-        if (const pigo_status ps = ensure_side_distinct(p, s)) return ps;
     // (k_scan_one with its own order restore writes the counts itself)
     const bool one_restore = variant == 3 && p->one_ok && p->one.restore && !p->guard && !p->scales.empty() && p->c->ntrees != 0;
     if (!one_restore) HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nframes * 4, s));
@@ -2020,7 +1973,8 @@ extern "C" pigo_status pigo_plan_run(pigo_plan *p, const uint8_t *d_frames, size
     if (!p) return fail(PIGO_ERR_PARAM, "plan is NULL");
     std::lock_guard<std::mutex> lock(p->mu);  // a plan owns one workspace: launches on it are serialised
     hipStream_t s = (hipStream_t)stream;
-    if (nframes < 1 || nframes > p->graph_max_frames || p->profiling || !p->cap_stream)
+    // (a plan of a few frames that runs as ONE launch -- k_scan_one -- has nothing a graph could save)
+    if (nframes < 1 || nframes > p->graph_max_frames || p->profiling || !p->cap_stream || (p->variant == 3 && p->one_ok))
         return plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, s, p->variant);
     // Small batch: ~10 dependent launches, memsets and stream joins cost more host time than GPU time.  The sequence only
     // depends on the buffers, so it is captured once (on an internal stream: the caller's may be the legacy default stream,
@@ -2034,8 +1988,12 @@ extern "C" pigo_status pigo_plan_run(pigo_plan *p, const uint8_t *d_frames, size
             gc.exec = nullptr;
         }
         hipGraph_t graph = nullptr;
+        // (the captured sequence stays on ONE stream: a fork onto the plan's side stream inside a capture, next to plan builds and
+        // frees on other threads, crashed inside the runtime about once in four runs of the parity suite -- pigo_run_cascade's slots)
         HIP_TRY(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
+        p->no_fork = true;
         const pigo_status st = plan_run_variant(p, d_frames, frame_stride, nframes, d_dets, d_counts, p->cap_stream, p->variant);
+        p->no_fork = false;
         const hipError_t e = hipStreamEndCapture(p->cap_stream, &graph);
         if (st != PIGO_OK) {
             if (graph) (void)hipGraphDestroy(graph);
@@ -2319,6 +2277,14 @@ pigo_status slot_enqueue(pigo_cascade::RunSlot &sl)
     // (the upload in pieces, each in flight while the next is copied into the staging buffer, measured flat: 0.292 vs 0.297 ms --
     // every hipMemcpyAsync costs the host what it hides)
     HIP_TRY(hipMemcpyAsync(sl.d_frame.p, sl.h_frame, sl.fbytes, hipMemcpyHostToDevice, sl.stream));
+    if (p->variant == 3 && p->one_ok && p->one.restore && !p->guard && !p->scales.empty() && p->c->ntrees != 0) {
+        // ONE launch whose last workgroup writes the ordered detections, the count and the flag words straight into the slot's
+        // pinned host buffers (device-visible): no copy behind the scan, one stream node less per result
+        p->one_host_flags = sl.h_small + 1;
+        const pigo_status st = plan_run_variant(p, sl.d_frame.p, sl.fbytes, 1, sl.h_dets, sl.h_small, sl.stream, p->variant);
+        p->one_host_flags = nullptr;
+        return st;
+    }
     pigo_status st = plan_run_variant(p, sl.d_frame.p, sl.fbytes, 1, sl.d_dets.p, sl.d_count.p, sl.stream, p->variant);
     if (st != PIGO_OK) return st;
     HIP_TRY(hipMemcpyAsync(sl.h_small, sl.d_count.p, 4, hipMemcpyDeviceToHost, sl.stream));
@@ -2420,6 +2386,10 @@ extern "C" pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, 
         int32_t n = sl->h_small[0];
         const int32_t fl_queue = sl->h_small[1], fl_panic = sl->h_small[2], fl_dets = sl->h_small[3];
         if (fl_queue || fl_panic || fl_dets) HIP_TRY(hipMemsetAsync(p->d_flags.p, 0, 16, sl->stream));
+        if (fl_queue && p->one_ok) {  // (k_scan_one: an overflowed queue or a hand-off that gave up may have left entries and counters behind)
+            HIP_TRY(hipMemsetAsync(p->d_onecnt.p, 0, (size_t)kOneCntWords * 4, sl->stream));
+            HIP_TRY(hipMemsetAsync(p->d_oneq.p, 0, (size_t)8 * p->one.qcap * sizeof(uint4), sl->stream));
+        }
         if (fl_panic) return fail(PIGO_ERR_PANIC, "the reference would panic: pixel index out of range in classifyRotatedRegion (pigo.go:167-179)");
         if (fl_queue) {  // pathological frame: more survivors than a queue holds -- the monolithic kernel has no queue
             st = plan_run_variant(p, sl->d_frame.p, fbytes, 1, sl->d_dets.p, sl->d_count.p, sl->stream, 0);

@@ -44,6 +44,8 @@ def main():
     print("  region phase timers (cycles per region, %d regions x runs): copy %.0f scan(wave 0) %.0f wait %.0f deep(per wave) %.0f total %.0f | deep windows/region %.1f" %
           (st[4], st[0] / nreg, st[1] / nreg, st[3] / nreg, st[2] / nreg / 16, st[5] / nreg, st[7] / nreg))
     print("  queue entries of the last run: %d" % plan.last_queue_count())
+    plan.run(dev, dets, counts)  # one more run on zeroed phase timers: the per-workgroup words then belong to ONE item each
+    torch.cuda.synchronize()
     tr = plan.debug_trace().astype(np.int64)
     # (the trace words accumulate nothing: every run overwrites them, [6] excepted)
     tr = tr[tr[:, 0] > 0]
@@ -65,6 +67,17 @@ def main():
     d = us(srt[:, 1]) - us(srt[:, 0])
     worst = np.argsort(-d)[:10]
     print("  slowest first items: " + ", ".join("item %d %.1f us" % (int(srt[i, 5]), d[i]) for i in worst))
+    # per-workgroup region phase timers (cycles, sums over the runs since the plan's debug_stats call: none, the words are copied at
+    # the end of each run): copy, scan (wave 0), deep (all waves / 16), wait, per region
+    def phases(i):
+        w = srt[i, 8:16].astype(np.float64)
+        n = max(w[4], 1.0)
+        return "copy %5.0f scan %6.0f wait %6.0f deep/wave %6.0f total %6.0f cyc, deep windows %4.0f passes %5.0f" % (w[0] / n, w[1] / n, w[3] / n, w[2] / n / 16, w[5] / n, w[7] / n, w[6] / n)
+    small = np.where(srt[:, 5] >= 96)[0]
+    if len(small):
+        so = small[np.argsort(-d[small])]
+        for i in list(so[:6]) + list(so[-4:]):
+            print("    item %3d %5.1f us: %s" % (int(srt[i, 5]), d[i], phases(i)))
     for lo, hi in ((0, 32), (32, 96), (96, 1 << 30)):
         m = (srt[:, 5] >= lo) & (srt[:, 5] < hi)
         if m.any():

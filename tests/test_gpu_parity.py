@@ -875,11 +875,10 @@ def test_run_cascade_is_reentrant_four_threads_one_handle(orc, graph, monkeypatc
 
 
 def test_one_frame_plans_in_a_process_full_of_streams(pg, orc):
-    """A process's HIP streams share a handful of hardware queues; plans of a few frames probe their side stream against the
-    caller's on the first call on it and replace it when the two share a queue (ensure_side_distinct).  Twelve live streams
-    and a live batch plan make collisions likely: one-frame plans then run on the default stream and on two of those streams,
-    several times each (first call = probe, later calls = plain), and a fresh handle serves RunCascade -- every result the
-    oracle's.  core/pigo.go:212-258."""
+    """A process's HIP streams share a handful of hardware queues.  Until round 4 a plan of a few frames forked onto a side
+    stream of its own and had to probe it against the caller's; now such a plan is ONE launch on the caller's stream
+    (k_scan_one).  Twelve live streams and a live batch plan: one-frame plans run on the default stream and on two of those
+    streams, several times each, and a fresh handle serves RunCascade -- every result the oracle's.  core/pigo.go:212-258."""
     import torch
     from pigo_amd import batch
     rows, cols = 480, 640
@@ -915,6 +914,79 @@ def test_one_frame_plans_in_a_process_full_of_streams(pg, orc):
         got = pg2.RunCascade(_cp(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1), 0.0)
         assert_same_dets(got, want[f], f"RunCascade next to {len(streams)} streams, frame {f}", Q_TOL_RAW)
     assert sum(len(w) for w in want) > 20
+
+
+@pytest.mark.parametrize("nframes,angle,kind", [(1, 0.0, "faces"), (3, 0.0, "faces"), (1, 0.8, "faces"), (7, 0.0, "noise")])
+def test_one_launch_plans_hand_off_under_uneven_load(pg, orc, nframes, angle, kind):
+    """Plans of fewer than 8 frames run as ONE persistent launch (k_scan_one: regions and big-scale chunks as items, survivors
+    handed to consumer waves of the same grid through global queues, the last workgroup restores the reference's order).  Its
+    in-launch hand-offs are exercised the way they fail: hundreds of launches NEXT TO a batch plan that keeps the chip busy on
+    another stream (workgroups of the launch start late and unevenly), every result compared with the first -- itself the
+    oracle's, record for record.  Two bugs of exactly this kind were found this way in round 5 (a consumer's claim overtaking
+    its read of the finished-items counter; a poison entry left for the next launch).  core/pigo.go:212-258."""
+    import torch
+    from pigo_amd import batch
+    rows, cols = 720, 1280
+    frames = synth.make_frames(kind, nframes, rows, cols, seed=31)
+    plan = batch.ScanPlan(pg, rows, cols, angle=angle, max_frames=nframes, det_cap=2048)
+    assert plan.info().variant == 3
+    dev = torch.from_numpy(frames).cuda()
+    dets, counts = plan.alloc_outputs(nframes)
+    plan.run(dev, dets, counts)
+    torch.cuda.synchronize()
+    plan.status()
+    got = batch.dets_to_numpy(dets, counts)
+    for f in range(nframes):
+        want = orc.run_cascade(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1, angle)
+        assert_same_dets(got[f], want, f"k_scan_one frame {f}", Q_TOL_RAW)
+    ref_d, ref_c = dets.clone(), counts.clone()
+    big = batch.ScanPlan(pg, rows, cols, max_frames=32, det_cap=1024)
+    bf = torch.from_numpy(synth.make_frames("faces", 32, rows, cols, seed=5)).cuda()
+    bd, bc = big.alloc_outputs(32)
+    side = torch.cuda.Stream()
+    for i in range(400):
+        if i % 8 == 0:
+            big.run(bf, bd, bc, stream=side)
+        dets.zero_()
+        plan.run(dev, dets, counts)
+        torch.cuda.current_stream().synchronize()
+        plan.status()
+        assert torch.equal(counts, ref_c) and torch.equal(dets, ref_d), f"launch {i} next to a busy batch plan differs from the first"
+    torch.cuda.synchronize()
+    big.status()
+
+
+def test_one_launch_plan_reports_a_queue_overflow(pg, monkeypatch):
+    """k_scan_one's global queues are sized for 1/32 of a frame's windows each; a frame that keeps more alive than that must
+    raise the plan's queue flag (PIGO_ERR_CAPACITY from pigo_plan_status), not hang and not drop windows silently -- and the
+    plan must be usable again afterwards (the status call clears queues and counters).  Forced here with a tiny queue."""
+    import torch
+    from pigo_amd import batch
+    monkeypatch.setenv("PIGO_TUNING", "1")
+    monkeypatch.setenv("PIGO_ONE_QCAP", "8")
+    rows, cols = 480, 640
+    frames = synth.make_frames("faces", 1, rows, cols, seed=9)
+    plan = batch.ScanPlan(pg, rows, cols, max_frames=1, det_cap=1024)
+    monkeypatch.delenv("PIGO_ONE_QCAP")
+    assert plan.info().variant == 3
+    dev = torch.from_numpy(frames).cuda()
+    dets, counts = plan.alloc_outputs(1)
+    plan.run(dev, dets, counts)
+    torch.cuda.synchronize()
+    with pytest.raises(core.PigoError):
+        plan.status()
+    assert plan.last_flags()[0] != 0
+    ok = batch.ScanPlan(pg, rows, cols, max_frames=1, det_cap=1024)
+    d2, c2 = ok.alloc_outputs(1)
+    ok.run(dev, d2, c2)
+    torch.cuda.synchronize()
+    ok.status()
+    assert int(c2[0]) > 0
+    # RunCascade on such a frame falls back to the kernel without a queue and still returns the reference's list
+    monkeypatch.setenv("PIGO_ONE_QCAP", "8")
+    pg2 = core.NewPigo(0).Unpack(synth.facefinder_bytes())
+    got = pg2.RunCascade(_cp(frames[0], rows, cols, cols, 20, 1000, 0.1, 1.1), 0.0)
+    assert_same_dets(got, batch.dets_to_numpy(d2, c2)[0], "RunCascade behind an overflowing k_scan_one queue", Q_TOL_RAW)
 
 
 @pytest.mark.parametrize("runs", [False] + ([True] if __import__("os").environ.get("PIGO_STRESS_FULL") else []))
