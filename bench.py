@@ -127,6 +127,9 @@ def cpu_dry_run(args, json_fd):
     seen = [None] * world
     dist.all_gather_object(seen, rank)
     ok = all(int(out[r * B + f, 0]) == (r * B + f) % (gcap + 2) for r in range(world) for f in range(B))
+    # ... and the flags word of every row: a list longer than the gather capacity is marked truncated, nothing else is raised
+    ok = ok and all(int(out[r * B + f, 1]) == (distributed.WIRE_TRUNCATED_GATHER if (r * B + f) % (gcap + 2) > gcap else 0)
+                    for r in range(world) for f in range(B))
     if rank == 0:
         os.write(json_fd, (json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "Mwindows/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(elapsed / (args.warmup + args.steps) * 1e3, 4), "dry_run": True,
@@ -388,7 +391,7 @@ def main():
                 comm, gather_mode = None, "torch (pigo_comm_init failed)"
             else:  # which collective the C ABI will issue: ncclAllGather, or (world 1 without an id) a device copy
                 gather_mode = "cabi/rccl" if comm.uses_rccl else "cabi/memcpy"
-        gathered = torch.zeros((world * B, 1 + 4 * gcap), dtype=torch.int32, device=dev)
+        gathered = torch.zeros((world * B, 2 + 4 * gcap), dtype=torch.int32, device=dev)
 
     def step():
         if comm is not None:  # scan + cluster + pack + ncclAllGather, all enqueued by libpigo_hip.so

@@ -298,9 +298,10 @@ inline std::pair<int, int> ShardBounds(int nframes, int rank, int world)
     return {lo, hi};
 }
 
-// one row of the all-gathered wire format -> the frame's (possibly truncated) list and its true length
-inline std::vector<Detection> UnpackList(const int32_t *wire_row, int gather_cap, int *true_count = nullptr)
+// one row of the all-gathered wire format -> the frame's (possibly truncated) list, its true length and its PIGO_WIRE_* flags
+inline std::vector<Detection> UnpackList(const int32_t *wire_row, int gather_cap, int *true_count = nullptr, int *flags = nullptr)
 {
+    if (flags) *flags = pigo_wire_row_flags(wire_row);
     std::vector<pigo_det> raw((size_t)(gather_cap > 0 ? gather_cap : 1));
     int n = 0, tc = 0;
     detail::check(pigo_unpack_list(wire_row, gather_cap, raw.data(), (int)raw.size(), &n, &tc), "pigo_unpack_list");

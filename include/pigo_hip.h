@@ -253,9 +253,10 @@ pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n);
 /* ---- multi-GPU batch: frames sharded over ranks + ONE RCCL all-gather (BASELINE config 3; no reference counterpart) ----
  * RunCascade is a single goroutine over one image (core/pigo.go:212-258) and frames are independent, so a batch is cut into
  * contiguous shards, one process per GPU, with no exchange during the scan; the per-frame lists are exchanged once at the
- * end.  RCCL has no all-gather-v: every frame travels as one fixed-size row of pigo_wire_words(gather_cap) = 1 + 4*gather_cap
- * int32 -- the TRUE count (count > gather_cap marks a truncated row), then the first min(count, gather_cap) pigo_det records,
- * zero-padded.  librccl is bound with dlopen at first use (PIGO_RCCL_LIB overrides the name).
+ * end.  RCCL has no all-gather-v: every frame travels as one fixed-size row of pigo_wire_words(gather_cap) = 2 + 4*gather_cap
+ * int32 -- the TRUE count, a FLAGS word (PIGO_WIRE_* below: what a peer must know about the row without asking the rank that made
+ * it), then the first min(count, gather_cap) pigo_det records, zero-padded.  librccl is bound with dlopen at first use
+ * (PIGO_RCCL_LIB overrides the name).
  *
  *   rank 0:      pigo_comm_unique_id(id)            -- ncclGetUniqueId; the host program ships the 128 bytes to every rank
  *   every rank:  pigo_comm_init(id, rank, world, device, &comm)   -- ncclCommInitRank (collective)
@@ -268,8 +269,8 @@ pigo_status pigo_plan_last_queue_count(pigo_plan *p, int64_t *n);
  * Errors: a rank whose scan fails inside pigo_run_batch_sharded still contributes zero-count padding rows to the collective
  * before it returns the error, so its peers do not hang.  Only SYNCHRONOUS refusals take that path (bad arguments, a launch
  * error): survivor-queue overflow and lists truncated at det_cap are raised on the device and reported by pigo_plan_status()
- * after the stream has been synchronised -- every rank must check it (a truncated list also shows in its wire row: the count
- * word holds the TRUE count).  pigo_comm_init waits for its peers with a deadline (PIGO_COMM_INIT_TIMEOUT_S, default 300 s,
+ * after the stream has been synchronised -- every rank should check it, and every PEER sees both in the flags word of that
+ * rank's rows (PIGO_WIRE_QUEUE_OVERFLOW, PIGO_WIRE_TRUNCATED_DETCAP), packed on the device behind the scan.  pigo_comm_init waits for its peers with a deadline (PIGO_COMM_INIT_TIMEOUT_S, default 300 s,
  * 0 = none) and returns PIGO_ERR_HIP when a peer does not join; a failed pigo_comm_init or collective is fatal for the
  * communicator on every rank: pigo_comm_abort (if a collective may be outstanding), pigo_comm_destroy, start over. */
 typedef struct pigo_comm pigo_comm;
@@ -286,6 +287,14 @@ void pigo_comm_destroy(pigo_comm *c);
 /* contiguous shard [lo, hi) of `nframes` frames for `rank`; earlier ranks take the remainder */
 void pigo_shard_bounds(int nframes, int rank, int world, int *lo, int *hi);
 size_t pigo_wire_words(int gather_cap);
+/* flags word of a wire row (row[1]) */
+#define PIGO_WIRE_TRUNCATED_GATHER 1 /* count > gather_cap: the row holds the first gather_cap records of the list */
+#define PIGO_WIRE_TRUNCATED_DETCAP 2 /* the producing rank's list (or the raw list its clusters were made from) was cut at det_cap: incomplete */
+#define PIGO_WIRE_QUEUE_OVERFLOW 4   /* the producing rank's scan overflowed a survivor queue: its lists may miss detections, rescan */
+#define PIGO_WIRE_WOULD_PANIC 8      /* a frame of the producing rank's batch makes the reference panic (pigo.go:167-179) */
+#define PIGO_WIRE_RANK_FAILED 16     /* the producing rank's scan was refused (bad arguments, launch error): all its rows are padding */
+#define PIGO_WIRE_PADDING 32         /* no frame behind this row (short shard) -- not "a frame without detections" */
+int pigo_wire_row_flags(const int32_t *wire_row);
 /* Scan (+ per-frame ClusterDetections when iou_threshold >= 0; a negative or NaN threshold gathers the raw RunCascade lists)
  * this rank's `nframes_local` device-resident frames and all-gather the wire rows of all ranks:
  *     d_gathered [world * frames_per_rank][pigo_wire_words(gather_cap)] int32, device memory; rank r's frames are rows

@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "pigo_rgb_to_grayscale", "pigo_gray_batch",
     "pigo_puploc_create", "pigo_puploc_info", "pigo_puploc_destroy", "pigo_puploc_run_detector", "pigo_get_landmark_point",
     "pigo_puploc_run_batch", "pigo_puploc_status",
-    "pigo_comm_unique_id", "pigo_comm_init", "pigo_comm_info", "pigo_comm_uses_rccl", "pigo_comm_abort", "pigo_comm_destroy", "pigo_shard_bounds", "pigo_wire_words",
+    "pigo_comm_unique_id", "pigo_comm_init", "pigo_comm_info", "pigo_comm_uses_rccl", "pigo_comm_abort", "pigo_comm_destroy", "pigo_shard_bounds", "pigo_wire_words", "pigo_wire_row_flags",
     "pigo_run_batch_sharded", "pigo_pack_lists", "pigo_unpack_list",
 ]
 
@@ -148,12 +148,14 @@ def load_library():
     L.pigo_shard_bounds.restype = None
     L.pigo_wire_words.argtypes = [i32]
     L.pigo_wire_words.restype = sz
+    L.pigo_wire_row_flags.argtypes = [vp]
+    L.pigo_wire_row_flags.restype = C.c_int
     L.pigo_run_batch_sharded.argtypes = [vp, vp, vp, sz, i32, i32, dbl, i32, vp, vp]
     L.pigo_pack_lists.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.pigo_unpack_list.argtypes = [vp, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("pigo_device_count", "pigo_plan_last_timings", "pigo_wire_words", "pigo_comm_uses_rccl"):
+        if fn.restype is C.c_int and name not in ("pigo_device_count", "pigo_plan_last_timings", "pigo_wire_words", "pigo_wire_row_flags", "pigo_comm_uses_rccl"):
             fn.restype = C.c_int
     _lib = L
     return L

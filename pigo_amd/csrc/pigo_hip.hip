@@ -1020,6 +1020,7 @@ bool build_region_groups(pigo_plan &p)
                 ((size_t)(k - k_lo) * t_pool * 64 + (size_t)nh * 128) * 4 >= (size_t)deep_cap_g * 8)
                 r.quad = want;
         r.compress = compress ? 1 : 0;
+        r.cut = env_int("PIGO_REG_CUT", 0);  // (read by the debug build only)
         r.one_local = one_mode ? std::max(0, std::min(8, env_int(g == 0 ? "PIGO_ONE_LOCAL0" : "PIGO_ONE_LOCAL1", 1))) : 0;
         r.wave_q = wq;
         for (int j = k_lo; j < k; ++j)
@@ -1090,6 +1091,8 @@ pigo_status build_big(pigo_plan &p)
         for (long long f0 = 0; f0 < nwin; f0 += kBigChunk) p.big_items.push_back(make_uint2((unsigned)k, (unsigned)f0));
     }
     if (p.big_items.empty() || p.big_items.size() > (1u << 24)) return PIGO_OK;
+    // (k_scan_big counts its work items -- chunks x the frames an XCD scans -- in 32 bits)
+    if ((unsigned long long)p.big_items.size() * (unsigned long long)((p.max_frames + 7) / 8) >= (1ull << 32)) return PIGO_OK;
     B.cpf = (uint32_t)p.big_items.size();
     p.big_lds = (size_t)kBigWaves * (kBigChunk * 6);
     // k_big_pool's input queues, one per XCD: room for a quarter of the big-scale windows of the frames an XCD scans (8 % survive
@@ -2772,6 +2775,7 @@ struct pigo_comm {
     int rank = 0, world = 1, device = 0;
     rccl_comm_t comm = nullptr;  // NULL when world == 1: nothing to exchange
     bool aborted = false;        // pigo_comm_abort was called: every further collective on it is refused
+    std::mutex mu;               // comm / aborted: pigo_comm_abort may come from another thread than the one enqueueing collectives
 };
 
 extern "C" pigo_status pigo_comm_unique_id(uint8_t id[PIGO_COMM_ID_BYTES])
@@ -2818,26 +2822,34 @@ extern "C" pigo_status pigo_comm_init(const uint8_t id[PIGO_COMM_ID_BYTES], int 
             struct InitState {
                 std::mutex mu;
                 std::condition_variable cv;
-                bool done = false;
+                bool done = false, abandoned = false;
                 int rc = 0;
                 rccl_comm_t comm = nullptr;
             };
             std::shared_ptr<InitState> stt = std::make_shared<InitState>();
             const fn_ncclCommInitRank init = r->init_rank;
-            std::thread([stt, init, world, u, rank, device]() {
+            const auto abort_fn = r->abort;
+            std::thread([stt, init, abort_fn, world, u, rank, device]() {
                 (void)hipSetDevice(device);
                 rccl_comm_t cm = nullptr;
                 const int rc = init(&cm, world, u, rank);
-                std::lock_guard<std::mutex> lock(stt->mu);
-                stt->rc = rc;
-                stt->comm = cm;
-                stt->done = true;
-                stt->cv.notify_all();
+                bool late = false;
+                {
+                    std::lock_guard<std::mutex> lock(stt->mu);
+                    stt->rc = rc;
+                    stt->comm = cm;
+                    stt->done = true;
+                    late = stt->abandoned;
+                    stt->cv.notify_all();
+                }
+                if (late && rc == 0 && cm && abort_fn) (void)abort_fn(cm);  // the waiter has given up: nobody owns this communicator
             }).detach();
             std::unique_lock<std::mutex> lock(stt->mu);
-            if (!stt->cv.wait_for(lock, std::chrono::seconds(timeout_s), [&] { return stt->done; }))
+            if (!stt->cv.wait_for(lock, std::chrono::seconds(timeout_s), [&] { return stt->done; })) {
+                stt->abandoned = true;
                 return fail(PIGO_ERR_HIP, "pigo_comm_init: rank %d of %d waited %d s for its peers in ncclCommInitRank (PIGO_COMM_INIT_TIMEOUT_S); "
                                           "a peer did not join -- this communicator cannot be used", rank, world, timeout_s);
+            }
             if (stt->rc != 0) return fail(PIGO_ERR_HIP, "ncclCommInitRank: %s", r->err ? r->err(stt->rc) : "rccl error");
             c->comm = stt->comm;
         }
@@ -2852,6 +2864,7 @@ extern "C" pigo_status pigo_comm_init(const uint8_t id[PIGO_COMM_ID_BYTES], int 
 extern "C" pigo_status pigo_comm_abort(pigo_comm *c)
 {
     if (!c) return fail(PIGO_ERR_PARAM, "comm is NULL");
+    std::lock_guard<std::mutex> lock(c->mu);
     if (!c->comm) return PIGO_OK;  // world 1 without an id: nothing in flight
     if (!g_rccl.abort) return fail(PIGO_ERR_HIP, "librccl has no ncclCommAbort");
     (void)hipSetDevice(c->device);
@@ -2892,7 +2905,9 @@ extern "C" void pigo_shard_bounds(int nframes, int rank, int world, int *lo, int
     if (hi) *hi = l + base + (rank < rem ? 1 : 0);
 }
 
-extern "C" size_t pigo_wire_words(int gather_cap) { return gather_cap < 0 ? 0 : 1 + 4 * (size_t)gather_cap; }
+extern "C" size_t pigo_wire_words(int gather_cap) { return gather_cap < 0 ? 0 : 2 + 4 * (size_t)gather_cap; }
+
+extern "C" int pigo_wire_row_flags(const int32_t *wire_row) { return wire_row ? wire_row[1] : 0; }
 
 extern "C" pigo_status pigo_pack_lists(const pigo_det *lists, const int32_t *counts, int nframes, int frames_out, int cap, int gather_cap,
                                        int32_t *wire)
@@ -2904,10 +2919,14 @@ extern "C" pigo_status pigo_pack_lists(const pigo_det *lists, const int32_t *cou
     for (int f = 0; f < frames_out; ++f) {
         int32_t *row = wire + (size_t)f * words;
         memset(row, 0, words * 4);
-        if (f >= nframes) continue;
+        if (f >= nframes) {
+            row[1] = PIGO_WIRE_PADDING;
+            continue;
+        }
         row[0] = counts[f];
+        row[1] = (counts[f] > gather_cap ? PIGO_WIRE_TRUNCATED_GATHER : 0) | (counts[f] > cap ? PIGO_WIRE_TRUNCATED_DETCAP : 0);
         const int n = std::max(0, std::min(std::min(counts[f], cap), gather_cap));
-        if (n) memcpy(row + 1, lists + (size_t)f * cap, (size_t)n * sizeof(pigo_det));
+        if (n) memcpy(row + 2, lists + (size_t)f * cap, (size_t)n * sizeof(pigo_det));
     }
     return PIGO_OK;
 }
@@ -2921,7 +2940,7 @@ extern "C" pigo_status pigo_unpack_list(const int32_t *wire_row, int gather_cap,
     if (n_out) *n_out = n;
     if (n > cap) return fail(PIGO_ERR_CAPACITY, "unpack: %d records, capacity %d", n, cap);
     if (n && !out) return fail(PIGO_ERR_PARAM, "out is NULL");
-    if (n) memcpy(out, wire_row + 1, (size_t)n * sizeof(pigo_det));
+    if (n) memcpy(out, wire_row + 2, (size_t)n * sizeof(pigo_det));
     return PIGO_OK;
 }
 
@@ -2934,7 +2953,11 @@ extern "C" pigo_status pigo_run_batch_sharded(pigo_plan *p, pigo_comm *comm, con
     if (gather_cap < 1 || gather_cap > p->det_cap) return fail(PIGO_ERR_PARAM, "gather_cap outside [1, det_cap]");
     if (!d_gathered) return fail(PIGO_ERR_PARAM, "d_gathered is NULL");
     const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
-    if (comm && comm->aborted) return fail(PIGO_ERR_PARAM, "the communicator was aborted (pigo_comm_abort): destroy it and build a new one");
+    {
+        std::unique_lock<std::mutex> cl;
+        if (comm) cl = std::unique_lock<std::mutex>(comm->mu);
+        if (comm && comm->aborted) return fail(PIGO_ERR_PARAM, "the communicator was aborted (pigo_comm_abort): destroy it and build a new one");
+    }
     if (comm && comm->device != p->c->device) return fail(PIGO_ERR_PARAM, "communicator and plan live on different devices");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(p->c->device));
@@ -2972,10 +2995,19 @@ extern "C" pigo_status pigo_run_batch_sharded(pigo_plan *p, pigo_comm *comm, con
     }
     const std::string first_error = st != PIGO_OK ? g_last_error : std::string();
     if (st == PIGO_OK) {
-        k_pack_lists<<<frames_per_rank, 256, 0, s>>>(lists, lcounts, nframes_local, p->det_cap, gather_cap, p->sh_wire.p);
+        // (the rows carry the plan's device flags as the scan in front of this launch left them: a peer sees an overflowed queue or
+        // a list cut at det_cap on THIS rank in the rows themselves, without trusting this host to call pigo_plan_status)
+        k_pack_lists<<<frames_per_rank, 256, 0, s>>>(lists, lcounts, clustered ? d_counts : nullptr, p->d_flags.p, nframes_local, p->det_cap, gather_cap, 0,
+                                                     p->sh_wire.p);
         if (hipGetLastError() != hipSuccess) st = fail(PIGO_ERR_HIP, "k_pack_lists launch failed");
     }
-    if (st != PIGO_OK) (void)hipMemsetAsync(p->sh_wire.p, 0, row_words * 4, s);  // zero-count padding rows
+    if (st != PIGO_OK) {  // zero-count padding rows that say why: PIGO_WIRE_RANK_FAILED
+        k_pack_lists<<<frames_per_rank, 256, 0, s>>>(p->sh_dets.p, d_counts, nullptr, nullptr, 0, p->det_cap, gather_cap, 1, p->sh_wire.p);
+        if (hipGetLastError() != hipSuccess) (void)hipMemsetAsync(p->sh_wire.p, 0, row_words * 4, s);
+    }
+    std::unique_lock<std::mutex> comm_lock;
+    if (comm) comm_lock = std::unique_lock<std::mutex>(comm->mu);  // (the enqueue, not the collective: pigo_comm_abort gets its turn right after)
+    if (comm && comm->aborted) return fail(PIGO_ERR_PARAM, "the communicator was aborted (pigo_comm_abort) while this call was preparing its rows");
     if (comm && comm->comm) {
         const Rccl *r = nullptr;
         const pigo_status rs = rccl_load(&r);

@@ -3,9 +3,10 @@
 Frames are independent (RunCascade has no cross-frame state, core/pigo.go:212-258), so the batch is
 split into contiguous shards with no exchange during the scan; the only collective is ONE all-gather of
 fixed-capacity per-frame detection records at the end (RCCL over xGMI when the backend is "nccl").
-RCCL has no all-gather-v, so each frame contributes ``1 + 4*gather_cap`` int32 words: the true count
-followed by ``gather_cap`` 16-byte records (row, col, scale, q-bits); frames with more detections than
-``gather_cap`` are visible as ``count > gather_cap``.
+RCCL has no all-gather-v, so each frame contributes ``2 + 4*gather_cap`` int32 words: the true count, a
+flags word (WIRE_* below: truncated at the gather capacity / at det_cap, the producing rank's queue overflow,
+would-panic, rank failed, padding row -- what a peer must know without asking the rank that made the row),
+then ``gather_cap`` 16-byte records (row, col, scale, q-bits).
 
 Two ways to run it, same wire format:
   * ``Comm`` + ``run_batch_sharded`` -- the C ABI (include/pigo_hip.h: pigo_comm_init / pigo_run_batch_sharded): scan,
@@ -29,18 +30,31 @@ def shard_bounds(nframes: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def pack_lists(dets, counts, gather_cap: int):
-    """dets int32 [n, cap, 4], counts int32 [n] -> int32 [n, 1 + 4*gather_cap] wire rows: the true count, then the first
-    min(count, gather_cap) records, zero-padded (the layout k_pack_lists / pigo_pack_lists produce)."""
+#: flags word of a wire row (include/pigo_hip.h PIGO_WIRE_*)
+WIRE_TRUNCATED_GATHER, WIRE_TRUNCATED_DETCAP, WIRE_QUEUE_OVERFLOW, WIRE_WOULD_PANIC, WIRE_RANK_FAILED, WIRE_PADDING = 1, 2, 4, 8, 16, 32
+WIRE_HEAD = 2  # words in front of a row's records: the true count, the flags
+
+
+def pack_lists(dets, counts, gather_cap: int, raw_counts=None, plan_flags=None):
+    """dets int32 [n, cap, 4], counts int32 [n] -> int32 [n, 2 + 4*gather_cap] wire rows: the true count, the flags word, then
+    the first min(count, gather_cap) records, zero-padded (the layout k_pack_lists / pigo_pack_lists produce).  raw_counts: the
+    RunCascade counts a clustered list was made from; plan_flags: the (queue, panic) flags of the scan, as last_flags() gives them."""
     import torch
     n, cap = dets.shape[0], dets.shape[1]
     if gather_cap > cap:
         raise ValueError(f"gather_cap {gather_cap} exceeds the lists' capacity {cap}")
     g = gather_cap
-    wire = torch.zeros((n, 1 + 4 * gather_cap), dtype=torch.int32, device=dets.device)
+    wire = torch.zeros((n, WIRE_HEAD + 4 * gather_cap), dtype=torch.int32, device=dets.device)
     wire[:, 0] = counts
+    cut = counts > cap
+    if raw_counts is not None:
+        cut = cut | (raw_counts > cap)
+    flags = (counts > g).to(torch.int32) * WIRE_TRUNCATED_GATHER + cut.to(torch.int32) * WIRE_TRUNCATED_DETCAP
+    if plan_flags is not None:
+        flags = flags + (WIRE_QUEUE_OVERFLOW if plan_flags[0] else 0) + (WIRE_WOULD_PANIC if plan_flags[1] else 0)
+    wire[:, 1] = flags
     keep = torch.arange(g, device=dets.device).unsqueeze(0) < counts.clamp(max=g).unsqueeze(1)  # [n, g]
-    wire[:, 1:1 + 4 * g] = (dets[:, :g, :] * keep.unsqueeze(-1).to(dets.dtype)).reshape(n, 4 * g)
+    wire[:, WIRE_HEAD:WIRE_HEAD + 4 * g] = (dets[:, :g, :] * keep.unsqueeze(-1).to(dets.dtype)).reshape(n, 4 * g)
     return wire
 
 
@@ -93,13 +107,13 @@ class Comm:
 def run_batch_sharded(plan, comm, frames, frames_per_rank: int, iou: float, gather_cap: int, out=None, stream=None):
     """pigo_run_batch_sharded: scan this rank's ``frames`` (uint8 [n, rows, dim] on the GPU, n <= frames_per_rank),
     cluster per frame (iou >= 0; a negative iou gathers the raw lists) and all-gather the wire rows of all ranks.
-    Returns the int32 [world*frames_per_rank, 1 + 4*gather_cap] tensor (``out`` to reuse it).  Asynchronous on the current
+    Returns the int32 [world*frames_per_rank, 2 + 4*gather_cap] tensor (``out`` to reuse it).  Asynchronous on the current
     stream; ``plan.status()`` applies after synchronising."""
     import torch
     from .batch import ScanPlan
     n, stride = plan._check_frames(frames) if frames is not None and frames.shape[0] else (0, plan.rows * plan.dim)
     world = comm.world if comm is not None else 1
-    words = 1 + 4 * int(gather_cap)
+    words = WIRE_HEAD + 4 * int(gather_cap)
     if out is None:
         out = torch.zeros((world * frames_per_rank, words), dtype=torch.int32, device=torch.device("cuda", plan.device))
     assert out.dtype == torch.int32 and out.is_cuda and out.is_contiguous() and tuple(out.shape) == (world * frames_per_rank, words)
@@ -110,11 +124,11 @@ def run_batch_sharded(plan, comm, frames, frames_per_rank: int, iou: float, gath
 
 
 def pack_lists_host(dets: np.ndarray, counts: np.ndarray, frames_out: int, gather_cap: int) -> np.ndarray:
-    """pigo_pack_lists on host arrays: dets DET_DTYPE [n, cap], counts int32 [n] -> int32 [frames_out, 1 + 4*gather_cap]."""
+    """pigo_pack_lists on host arrays: dets DET_DTYPE [n, cap], counts int32 [n] -> int32 [frames_out, 2 + 4*gather_cap]."""
     dets = np.ascontiguousarray(dets)
     counts = np.ascontiguousarray(counts, dtype=np.int32)
     n, cap = dets.shape
-    wire = np.zeros((frames_out, 1 + 4 * gather_cap), dtype=np.int32)
+    wire = np.zeros((frames_out, WIRE_HEAD + 4 * gather_cap), dtype=np.int32)
     core.check(core.load_library().pigo_pack_lists(dets.ctypes.data, counts.ctypes.data, n, frames_out, cap, gather_cap, wire.ctypes.data),
                "pack_lists")
     return wire
@@ -137,18 +151,25 @@ def unpack_lists(wire, gather_cap: int):
     out = []
     for f in range(w.shape[0]):
         n = min(int(counts[f]), gather_cap)
-        out.append(np.ascontiguousarray(w[f, 1:1 + 4 * n]).view(core.DET_DTYPE).reshape(n).copy())
+        out.append(np.ascontiguousarray(w[f, WIRE_HEAD:WIRE_HEAD + 4 * n]).view(core.DET_DTYPE).reshape(n).copy())
     return out, counts
+
+
+def row_flags(wire):
+    """The flags words of gathered rows (tensor or array [rows, words]) as a NumPy array: WIRE_* bits."""
+    w = wire.cpu().numpy() if hasattr(wire, "cpu") else np.asarray(wire)
+    return w[:, 1].copy()
 
 
 def allgather_lists(dets, counts, gather_cap: int, frames_per_rank: int, group=None):
     """All-gather every rank's per-frame lists.  Every rank must pass exactly `frames_per_rank` frames'
-    worth of rows (pad short shards with zero-count frames).  Returns int32 [world*frames_per_rank, 1+4*gather_cap]."""
+    worth of rows (pad short shards with zero-count frames).  Returns int32 [world*frames_per_rank, 2+4*gather_cap]."""
     import torch
     import torch.distributed as dist
     wire = pack_lists(dets, counts, gather_cap)
     if wire.shape[0] < frames_per_rank:
         pad = torch.zeros((frames_per_rank - wire.shape[0], wire.shape[1]), dtype=wire.dtype, device=wire.device)
+        pad[:, 1] = WIRE_PADDING
         wire = torch.cat([wire, pad], dim=0)
     world = dist.get_world_size(group)
     out = torch.empty((world * frames_per_rank, wire.shape[1]), dtype=wire.dtype, device=wire.device)

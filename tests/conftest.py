@@ -7,7 +7,11 @@ import pytest
 
 # the parity suite forces schedule variants, queue sizes and code paths through the library's tuning switches: those are only
 # honoured with PIGO_TUNING=1 (pigo_hip.hip: env_int)
-os.environ.setdefault("PIGO_TUNING", "1")
+# (PIGO_TEST_NO_TUNING=1 -- tests/test_gpu_production_env.py -- runs the suite the way production runs the library: switches inert)
+if os.environ.get("PIGO_TEST_NO_TUNING") == "1":
+    os.environ.pop("PIGO_TUNING", None)
+else:
+    os.environ.setdefault("PIGO_TUNING", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

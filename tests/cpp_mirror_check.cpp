@@ -57,13 +57,13 @@ int main(int argc, char **argv)
             for (int i = 0; i < 16; ++i) lists[(size_t)i] = pigo_det{i, 2 * i, 3 * i, 0.5f * (float)i};
             std::vector<int32_t> wire(3 * pigo_wire_words(gcap));
             pigo::detail::check(pigo_pack_lists(lists.data(), counts, 2, 3, 8, gcap, wire.data()), "pigo_pack_lists");
-            int tc = -1;
-            const auto l0 = pigo::UnpackList(wire.data(), gcap, &tc);
-            wire_ok = wire_ok && l0.size() == 2 && tc == 2 && l0[1].Row == 1 && l0[1].Col == 2 && l0[1].Q == 0.5f;
-            const auto l1 = pigo::UnpackList(wire.data() + pigo_wire_words(gcap), gcap, &tc);
-            wire_ok = wire_ok && l1.size() == 4 && tc == 6 && l1[3].Row == 11;
-            const auto l2 = pigo::UnpackList(wire.data() + 2 * pigo_wire_words(gcap), gcap, &tc);
-            wire_ok = wire_ok && l2.empty() && tc == 0;  // padding row
+            int tc = -1, fl = -1;
+            const auto l0 = pigo::UnpackList(wire.data(), gcap, &tc, &fl);
+            wire_ok = wire_ok && l0.size() == 2 && tc == 2 && fl == 0 && l0[1].Row == 1 && l0[1].Col == 2 && l0[1].Q == 0.5f;
+            const auto l1 = pigo::UnpackList(wire.data() + pigo_wire_words(gcap), gcap, &tc, &fl);
+            wire_ok = wire_ok && l1.size() == 4 && tc == 6 && fl == PIGO_WIRE_TRUNCATED_GATHER && l1[3].Row == 11;
+            const auto l2 = pigo::UnpackList(wire.data() + 2 * pigo_wire_words(gcap), gcap, &tc, &fl);
+            wire_ok = wire_ok && l2.empty() && tc == 0 && fl == PIGO_WIRE_PADDING;  // padding row
         }
         std::printf(" wire_ok=%d", wire_ok ? 1 : 0);
         std::printf("\n");

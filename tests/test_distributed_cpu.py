@@ -64,7 +64,11 @@ def _worker_cabi(rank, world, port, nframes, cap, gcap, ret):
         wire = distributed.pack_lists_host(dets.numpy().view(core.DET_DTYPE).reshape(hi.value - lo.value, cap), counts.numpy(), per, gcap)
         ok &= wire.shape == (per, int(L.pigo_wire_words(gcap)))
         ref = distributed.pack_lists(dets, counts, gcap).numpy()  # the torch path writes the same rows
-        ok &= bool((wire[: hi.value - lo.value] == ref).all()) and bool((wire[hi.value - lo.value:] == 0).all())
+        nloc = hi.value - lo.value
+        ok &= bool((wire[:nloc] == ref).all())
+        # padding rows: count 0, no records, and the flags word says so (a frame WITHOUT detections has flags 0)
+        ok &= bool((wire[nloc:, 0] == 0).all()) and bool((wire[nloc:, 1] == distributed.WIRE_PADDING).all()) and bool((wire[nloc:, 2:] == 0).all())
+        ok &= all(int(L.pigo_wire_row_flags(wire[r].ctypes.data)) == int(wire[r, 1]) for r in range(per))
         out = torch.empty((world * per, wire.shape[1]), dtype=torch.int32)
         dist.all_gather_into_tensor(out, torch.from_numpy(wire))
         for row, f in enumerate(idx.tolist()):
@@ -165,6 +169,19 @@ def test_pack_unpack_roundtrip():
     wire = distributed.pack_lists(dets, counts, 8)
     lists, cnt = distributed.unpack_lists(wire, 8)
     assert cnt.tolist() == counts.tolist()  # the true counts survive, even when > gather_cap
+    # the flags word: cut at the gather capacity (count > 8), cut at the lists' capacity (count > 12) -- torch and C ABI agree
+    fl = distributed.row_flags(wire)
+    for f in range(5):
+        want = (distributed.WIRE_TRUNCATED_GATHER if int(counts[f]) > 8 else 0) | (distributed.WIRE_TRUNCATED_DETCAP if int(counts[f]) > 12 else 0)
+        assert int(fl[f]) == want, (f, int(counts[f]), int(fl[f]))
+    host = distributed.pack_lists_host(dets.numpy().view(core.DET_DTYPE).reshape(5, 12), counts.numpy(), 6, 8)
+    assert (host[:5] == wire.numpy()).all() and int(host[5, 1]) == distributed.WIRE_PADDING
+    # a rank whose scan overflowed a queue or met a would-panic frame says so in every row
+    fl2 = distributed.row_flags(distributed.pack_lists(dets, counts, 8, plan_flags=(2, 1)))
+    assert all(int(v) & distributed.WIRE_QUEUE_OVERFLOW and int(v) & distributed.WIRE_WOULD_PANIC for v in fl2)
+    # clusters made from a raw list that was cut at det_cap are incomplete as well
+    fl3 = distributed.row_flags(distributed.pack_lists(dets, counts.clamp(max=3), 8, raw_counts=counts))
+    assert [bool(int(v) & distributed.WIRE_TRUNCATED_DETCAP) for v in fl3] == [int(c) > 12 for c in counts]
     for f, l in enumerate(lists):
         assert len(l) == min(int(counts[f]), 8) and l.dtype == core.DET_DTYPE
     import pytest

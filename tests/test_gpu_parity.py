@@ -748,9 +748,10 @@ def test_sharded_entry_point_world1_matches_plain_path(pg, orc, rccl):
         wire = distributed.run_batch_sharded(plan, comm, d_frames, per, iou, gcap)
         torch.cuda.synchronize()
         plan.status()
-        ref = distributed.pack_lists(lists, lcounts, gcap)
-        assert tuple(wire.shape) == (per, 1 + 4 * gcap)
-        assert torch.equal(wire[:n], ref) and int(wire[n:].abs().sum()) == 0
+        ref = distributed.pack_lists(lists, lcounts, gcap, raw_counts=counts)
+        assert tuple(wire.shape) == (per, 2 + 4 * gcap)
+        assert torch.equal(wire[:n], ref)
+        assert int(wire[n:, 0].abs().sum()) == 0 and int(wire[n:, 2:].abs().sum()) == 0 and bool((wire[n:, 1] == distributed.WIRE_PADDING).all())
         host = distributed.pack_lists_host(batch_lists_to_host(lists, n), lcounts.cpu().numpy(), per, gcap)
         assert (host == wire.cpu().numpy()).all()
     want0 = orc.cluster_detections(orc.run_cascade(frames[0], rows, cols, cols, 20, 1000, 0.1, 1.1, 0.0), 0.2)
@@ -769,12 +770,14 @@ def test_sharded_rank_with_a_failing_scan_still_joins_the_collective(pg):
     d_frames = torch.from_numpy(synth.make_frames("faces", n + 1, rows, cols, seed=5)).cuda()
     plan = batch.ScanPlan(pg, rows, cols, max_frames=4, det_cap=256)
     comm = distributed.Comm(0, 1, 0, distributed.Comm.unique_id())
-    out = torch.full((per, 1 + 4 * gcap), 7, dtype=torch.int32, device="cuda")
+    out = torch.full((per, 2 + 4 * gcap), 7, dtype=torch.int32, device="cuda")
     bad = d_frames.view(-1)[1:1 + n * rows * cols].view(n, rows, cols)  # frame pointer not a multiple of 4: pigo_plan_run refuses
     with pytest.raises(ValueError):
         distributed.run_batch_sharded(plan, comm, bad, per, 0.2, gcap, out=out)
     torch.cuda.synchronize()
-    assert int(out.abs().sum()) == 0  # the collective ran, with padding rows
+    # the collective ran, with padding rows that tell every peer why: PIGO_WIRE_RANK_FAILED
+    assert int(out[:, 0].abs().sum()) == 0 and int(out[:, 2:].abs().sum()) == 0
+    assert bool((out[:, 1] == (distributed.WIRE_RANK_FAILED | distributed.WIRE_PADDING)).all())
     wire = distributed.run_batch_sharded(plan, comm, d_frames[:n], per, 0.2, gcap, out=out)  # the communicator is still usable
     torch.cuda.synchronize()
     plan.status()
@@ -820,13 +823,28 @@ def test_comm_abort_and_init_deadline(pg, monkeypatch):
     with pytest.raises(ValueError):
         distributed.run_batch_sharded(plan, comm, d_frames, n, 0.2, gcap)
     del comm
-    if os.environ.get("PIGO_TEST_COMM_DEADLINE") != "1":
-        return  # (the timed-out rank's helper thread stays blocked inside RCCL until the process ends: run on request only)
-    monkeypatch.setenv("PIGO_COMM_INIT_TIMEOUT_S", "3")
-    t0 = time.time()
-    with pytest.raises(core.PigoError):
-        distributed.Comm(0, 2, 0, distributed.Comm.unique_id())
-    assert 2.0 < time.time() - t0 < 60.0
+    # The deadline, in a process of its own: the timed-out rank's helper thread stays blocked inside ncclCommInitRank until its
+    # process ends, so the child reports and leaves with os._exit -- nothing of it survives into this suite.
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, time\n"
+            "sys.path.insert(0, %r)\n"
+            "os.environ['PIGO_COMM_INIT_TIMEOUT_S'] = '3'\n"
+            "from pigo_amd import core, distributed\n"
+            "uid = distributed.Comm.unique_id()\n"
+            "t0 = time.time()\n"
+            "try:\n"
+            "    distributed.Comm(0, 2, 0, uid)\n"
+            "    print('NO_ERROR', flush=True)\n"
+            "except core.PigoError as e:\n"
+            "    print('DEADLINE %%.2f %%s' %% (time.time() - t0, e), flush=True)\n"
+            "os._exit(0)\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    line = [l for l in r.stdout.splitlines() if l.startswith(("DEADLINE", "NO_ERROR"))]
+    assert r.returncode == 0 and line and line[0].startswith("DEADLINE"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    waited = float(line[0].split()[1])
+    assert 2.0 < waited < 60.0, line[0]  # PIGO_ERR_HIP after ~3 s instead of hanging: world 2, only rank 0 ever shows up
 
 
 def batch_lists_to_host(lists, n):
