@@ -48,7 +48,8 @@ def main():
             if c in rows:
                 us, v = rows[c]
                 print("%-30s %10.1f | %s" % (NAMES[c], us or -1, " ".join("%18.4g" % v.get(k, float('nan')) for k in CTRS)))
-        print("-- what each stage adds (difference to the previous cut); LDS busy = IDX_ACTIVE / 256 CUs / kernel cycles (GRBM_GUI_ACTIVE); conflict share = BANK_CONFLICT / IDX_ACTIVE")
+        print("-- what each stage adds (difference to the previous cut); cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs); LDS busy = IDX_ACTIVE / 256 CUs / cycles; "
+              "VALU busy = INSTS_VALU x 2 cycles (wave64 on a SIMD-32) / 1024 SIMDs / cycles; conflict share = BANK_CONFLICT / IDX_ACTIVE")
         prev = None
         for c in CUTS:
             if c not in rows:
@@ -60,10 +61,10 @@ def main():
                 dus = us - prev[0]
                 dv = {k: v.get(k, 0) - prev[1].get(k, 0) for k in CTRS}
             ia, bc, il, iv = dv.get("SQ_LDS_IDX_ACTIVE", 0), dv.get("SQ_LDS_BANK_CONFLICT", 0), dv.get("SQ_INSTS_LDS", 0), dv.get("SQ_INSTS_VALU", 0)
-            cyc = dv.get("GRBM_GUI_ACTIVE", 0)
-            print("%-30s %9.1f us (%4.1f %%) | LDS insts %.4g  LDS cycles/inst %.2f  conflict share %.2f  LDS busy %.2f | VALU insts %.4g  VALU busy (4 cyc/inst/SIMD) %.2f | LDS cycles per CU %.4g of %.4g" %
+            cyc = dv.get("GRBM_GUI_ACTIVE", 0) / 8.0
+            print("%-30s %9.1f us (%4.1f %%) | LDS insts %.4g  LDS cycles/inst %.2f  conflict share %.2f  LDS busy %.2f | VALU insts %.4g  VALU busy %.2f | per CU: LDS cycles %.4g + VALU cycles %.4g = %.4g against %.4g measured" %
                   (NAMES[c] if prev is None else NAMES[c].lstrip("+ "), dus, 100.0 * dus / rows[0][0] if 0 in rows else 0, il, ia / max(il, 1), bc / max(ia, 1), ia / 256 / max(cyc, 1),
-                   iv, iv * 4 / 1024 / max(cyc, 1), ia / 256, cyc))
+                   iv, iv * 2 / 1024 / max(cyc, 1), ia / 256, iv * 2 / 1024, ia / 256 + iv * 2 / 1024, cyc))
             prev = (us, v)
         print()
 
