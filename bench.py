@@ -671,9 +671,9 @@ def main():
         # (separate rocprofv3 --pmc passes, profiles/rNN_traffic.json) gives FABRIC-side bytes per frame -- what the L2s missed,
         # Infinity-Cache hits included -- scaled here to this batch.  It is an upper bound of the HBM bytes.
         traffic, tnote, tsrc = None, None, None
-        tname = {3: "r04_traffic.json", 2: "r01_traffic.json"}.get(int(info.variant))
+        tname = {3: "r05_traffic.json", 2: "r01_traffic.json"}.get(int(info.variant))
         tpath = os.path.join(ROOT, "profiles", tname) if tname else None
-        for older in ("r03_traffic.json", "r02_traffic.json"):
+        for older in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
             if tpath and not os.path.exists(tpath) and int(info.variant) == 3:
                 tname = older
                 tpath = os.path.join(ROOT, "profiles", tname)
@@ -683,10 +683,13 @@ def main():
             traffic = int(trec.get("fabric_bytes_per_frame", trec.get("hbm_bytes_per_frame"))) * B
             tsrc = {"file": f"profiles/{tname}", "commit": trec.get("commit"), "frames_per_step_profiled": trec.get("frames_per_step"),
                     "fabric_bytes_per_frame": int(trec.get("fabric_bytes_per_frame", 0)),
+                    "ea_read_bytes_per_frame": trec.get("ea_read_bytes_per_frame_64B_requests"),
+                    "dram_destined_share_of_read_requests": trec.get("dram_destined_share_of_read_requests"),
                     "l2_hit_rate": {k.split("<")[0]: v.get("hit_rate") for k, v in (trec.get("l2_per_step") or {}).items()}}
             tnote = (f"profiled offline (profiles/{tname}, commit {trec.get('commit')}): L2-miss (fabric-side) bytes of the scan kernels = 2 x FETCH_SIZE + WRITE_SIZE per frame, "
                      "separate rocprofv3 --pmc passes, x frames; FETCH_SIZE x 2 agrees with TCC_MISS_sum x 128 B on these byte gathers; "
-                     "includes Infinity-Cache hits (a 128-frame batch is 265 MB), so an upper bound of the HBM bytes")
+                     f"profiled on {trec.get('frames_per_step')} frames per step; the Infinity Cache sits behind the counted interface (no counter of this stack "
+                     "separates its hits), so an upper bound of the HBM bytes")
         out = {
             "metric": "Mwindows/s (1080p facefinder scan, shift 0.1 / scale 1.1)" if (args.rows, args.cols) == (1080, 1920) else "Mwindows/s",
             "value": round(fps * wpf / 1e6, 3),
@@ -733,10 +736,10 @@ def main():
                 "traffic_note": tnote,
                 "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "compulsory bytes only (each frame read once + 16 B per detection); the scan is not bound by HBM: the region kernel by its "
-                        "LDS pipe (~62 % busy, ~47 % of that bank conflicts of divergent byte gathers), the 1 % largest windows -- gathered from "
-                        "global memory by the side chain that runs NEXT to the region workgroups -- by the L1 fill path (a 128-byte line per "
-                        "gathered byte) -- DESIGN.md section 4",
+                "note": "compulsory bytes only (each frame read once + 16 B per detection); the scan is not bound by HBM: the region kernel's time is "
+                        "its LDS cycles (68 % of the time; 48 % of them bank conflicts of divergent byte gathers, as the bank model predicts) plus its "
+                        "VALU cycles (37 %) within 5 % -- profiles/r05_region_model.md; the 1 % largest windows -- gathered from global memory by the "
+                        "side chain that runs NEXT to the region workgroups -- by the L1 fill path (a 128-byte line per gathered byte) -- DESIGN.md section 4",
             },
         }
         out["config3_shard"] = shard_leg
