@@ -111,6 +111,8 @@ struct pigo_cascade {
     DevBuf<uint8_t> d_frame;
     DevBuf<pigo_det> d_dets, d_sorted, d_clusters;
     DevBuf<int32_t> d_small;             // counts etc.
+    pigo_det *h_cl = nullptr;            // pinned host staging of pigo_cluster_detections' short lists: [in | out | counts]
+    hipStream_t cl_stream = nullptr;
     DevBuf<int32_t> d_cl_seeds, d_cl_tmpn;   // long lists: k_cluster_seeds / _members / _compact
     DevBuf<pigo_det> d_cl_tmp;
     DevBuf<float> d_mq;
@@ -429,6 +431,8 @@ extern "C" void pigo_cascade_destroy(pigo_cascade *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->cl_stream) (void)hipStreamDestroy(c->cl_stream);
+    if (c->h_cl) (void)hipHostFree(c->h_cl);
     delete c;
 }
 
@@ -2234,6 +2238,31 @@ extern "C" pigo_status pigo_cluster_detections(pigo_cascade *c, pigo_det *dets, 
     pigo_sort_by_q(dets, n);     // pigo.go:264-266, in place like the reference
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    if (n <= kClusterStaged && env_int("PIGO_CLUSTER_V2", -1) < 0) {
+        // a short list (what one frame yields): ONE launch that reads the sorted list from pinned host memory into LDS and writes the
+        // clusters and their number back to pinned host memory, one synchronisation -- no copy in front of or behind the kernel
+        if (!c->h_cl) {
+            HIP_TRY(hipHostMalloc((void **)&c->h_cl, (size_t)kClusterStaged * sizeof(pigo_det) * 2 + 64, hipHostMallocDefault));
+            HIP_TRY(hipStreamCreateWithFlags(&c->cl_stream, hipStreamNonBlocking));
+        }
+        pigo_det *h_in = c->h_cl, *h_out = c->h_cl + kClusterStaged;
+        int32_t *h_cnt = reinterpret_cast<int32_t *>(c->h_cl + 2 * kClusterStaged);  // [0] n, [1] clusters
+        memcpy(h_in, dets, (size_t)n * sizeof(pigo_det));
+        h_cnt[0] = n;
+        h_cnt[1] = -1;
+        k_cluster<256, true><<<1, 256, 0, c->cl_stream>>>(h_in, h_cnt, kClusterStaged, iou_threshold, h_out, h_cnt + 1, nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->cl_stream));
+        const int32_t ncl = h_cnt[1];
+        if (ncl < 0) return fail(PIGO_ERR_HIP, "ClusterDetections: the kernel left no result");
+        if (n_out) *n_out = ncl;
+        if (ncl > cap) return fail(PIGO_ERR_CAPACITY, "ClusterDetections: %d clusters, capacity %d", ncl, cap);
+        if (ncl > 0) {
+            if (!out) return fail(PIGO_ERR_PARAM, "out is NULL");
+            memcpy(out, h_out, (size_t)ncl * sizeof(pigo_det));
+        }
+        return PIGO_OK;
+    }
     if (c->d_sorted.n < (size_t)n) HIP_TRY(c->d_sorted.alloc(n));
     if (c->d_clusters.n < (size_t)n) HIP_TRY(c->d_clusters.alloc(n));
     if (c->d_mq.n < (size_t)n) HIP_TRY(c->d_mq.alloc(n));
