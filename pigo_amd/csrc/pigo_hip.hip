@@ -244,6 +244,7 @@ struct pigo_plan {
     int side_mode = 1;
     int fork_min_frames = 8;             // batches of at least this many frames run their tile classes on separate streams
     bool small_ct = false;               // plans of a few frames: k_tail_deep as one table-free launch (launch_tail)
+    int big_chunk = 128;                 // frames per pass of the side chain over the batch (0: the whole batch at once)
     bool no_fork = false;                // (while pigo_plan_run captures a graph) every launch stays on the one stream
     bool split_tail = false;             // plans of a few frames: the global-gather class and the LDS classes each with a queue set and a tail
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -1112,6 +1113,7 @@ pigo_status build_big(pigo_plan &p)
     p.big_ct = env_int("PIGO_BIG_CT", 1) != 0 && c.d_codes_t.p != nullptr;
     p.big_side_first = env_int("PIGO_BIG_FIRST", 0) != 0;
     p.big_skip = env_int("PIGO_BIG_SKIP", 0);
+    p.big_chunk = std::max(0, env_int("PIGO_BIG_CHUNK_FRAMES", 128)) & ~7;
     if (nh < nt) {
         const int wmax = p.big_ct ? nt : std::max(64, std::min(600, env_int("PIGO_BIG_DEEP_SPLIT", 192)));
         for (int t = nh; t < nt; t += wmax) p.side_splits.push_back(t);
@@ -1779,7 +1781,28 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             const bool reg_early = !p.big_side_first && p.big_ok;
             if (reg_early) launch_tiles<ROT, GUARD>(p, ab, xcd_cap, s, mark, true, 1);
             if (p.big_ok) {
-                launch_big<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, sa, mark);
+                // The chain walks the batch in chunks of big_chunk frames (128; a multiple of 8: the XCD dealing), its three launches
+                // per chunk: an XCD's k_tail_deep queue then holds at most 16 frames' entries instead of nframes / 8.  The tail's waves
+                // take their entries with a static stride and drift apart over the queue -- one wave sits on a face window for a dozen
+                // passes while its neighbours finish ten entries --, i.e. over the FRAMES it holds in order: with 64 frames per queue
+                // (a 512-frame step) its L2 hit rate was 0.69 and the chain's fabric traffic 90 MB per frame, with 8 frames 0.91 and
+                // 27 MB (profiles/r04_traffic.json, r05_experiments.md section 4).  Timing: the chain is hidden behind the region
+                // launches either way (1,024 frames: tail 17.1 -> 14.9 ms, k_scan_big 4.1 -> 5.6 -- a persistent kernel's ramp per
+                // chunk --, step 41.4 / 41.7 ms); chunks of 64 / 32 frames cost the step 1-3 % / 10 %.  Entries handed out in queue
+                // order from a counter instead (one atomic per entry on the wave's critical path): tail 1.83 -> 3.00 ms, removed.
+                const int per = p.big_chunk > 0 ? p.big_chunk : a.nframes;
+                for (int f0 = 0; f0 < a.nframes; f0 += per) {
+                    ScanArgs ac = aa;
+                    ac.nframes = std::min(per, a.nframes - f0);
+                    ac.frames = a.frames + (size_t)f0 * a.frame_stride;
+                    ac.counts = a.counts + f0;
+                    ac.raw = a.raw + (size_t)f0 * a.det_cap;
+                    if (f0 > 0) {  // the chain's counters: queues [0, 16), k_scan_big / k_big_pool's [40, 64)
+                        (void)hipMemsetAsync(ac.qcount, 0, 16 * sizeof(uint32_t), sa);
+                        (void)hipMemsetAsync(ac.qcount + 40, 0, 24 * sizeof(uint32_t), sa);
+                    }
+                    launch_big<ROT, GUARD>(p, ac, xcd_cap, p.d_queue2.p, (uint32_t)half2, sa, mark);
+                }
             } else {
                 launch_tiles<ROT, GUARD>(p, aa, xcd_cap, sa, mark, true, 6);
                 launch_tail<ROT, GUARD>(p, aa, xcd_cap, p.d_queue2.p, (uint32_t)half2, sa, mark, p.tile_patch);
@@ -2099,13 +2122,20 @@ extern "C" int pigo_plan_last_timings(pigo_plan *p, const char **names, float *m
 {
     if (!p || p->n_timed < 2) return 0;
     (void)hipSetDevice(p->c->device);
+    // (launches of one kind are summed: the side chain walks a large batch in chunks, three launches each)
     int n = 0;
-    for (int i = 0; i + 1 < p->n_timed && n < cap; ++i) {
+    for (int i = 0; i + 1 < p->n_timed; ++i) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, p->events[i], p->events[i + 1]) != hipSuccess) return n;
-        names[n] = p->ev_names[i];
-        ms[n] = t;
-        ++n;
+        int k = 0;
+        while (k < n && strcmp(names[k], p->ev_names[i]) != 0) ++k;
+        if (k == n) {
+            if (n >= cap) continue;
+            names[n] = p->ev_names[i];
+            ms[n] = 0.f;
+            ++n;
+        }
+        ms[k] += t;
     }
     return n;
 }
