@@ -1015,7 +1015,7 @@ def test_slot_capture_next_to_plan_builds_on_other_handles(orc, runs, monkeypatc
     is invalidated on the way.  plan_build now stays on a private stream (no device-wide call, nothing on the null stream), so
     slot builds, plan builds and hipMalloc-heavy calls on OTHER handles may run next to a capture without a process lock.
     (runs=True -- only with PIGO_STRESS_FULL=1 -- also scans batches on those other plans from the legacy null stream while
-    the capture is going on: scripts/gpu_r3_stress.py has the variations of that, DESIGN.md the status.)"""
+    the capture is going on; the round-3 stress script that drove the variations of that is gone with its round.)"""
     import threading
     import torch
     from pigo_amd import batch
