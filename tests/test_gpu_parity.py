@@ -974,6 +974,28 @@ def test_one_launch_plans_hand_off_under_uneven_load(pg, orc, nframes, angle, ki
     big.status()
 
 
+def test_one_launch_plan_with_a_list_too_long_for_its_own_order_restore(pg, orc):
+    """k_scan_one's last workgroup ranks the detections out of its LDS (<= 16,384 per frame); a plan with a larger det_cap keeps
+    k_restore_order behind the launch and zeroes the launch's counters from the host instead -- the other half of launch_scan's
+    one-launch branch.  Two frames, twice (the second run starts from what the first left)."""
+    import torch
+    from pigo_amd import batch
+    rows, cols = 480, 640
+    frames = synth.make_frames("faces", 2, rows, cols, seed=21)
+    plan = batch.ScanPlan(pg, rows, cols, max_frames=2, det_cap=20000)
+    assert plan.info().variant == 3
+    dev = torch.from_numpy(frames).cuda()
+    dets, counts = plan.alloc_outputs(2)
+    for _ in range(2):
+        dets.zero_()
+        plan.run(dev, dets, counts)
+        torch.cuda.synchronize()
+        plan.status()
+        got = batch.dets_to_numpy(dets, counts)
+        for f in range(2):
+            assert_same_dets(got[f], orc.run_cascade(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1, 0.0), f"det_cap 20000, frame {f}", Q_TOL_RAW)
+
+
 def test_one_launch_plan_reports_a_queue_overflow(pg, monkeypatch):
     """k_scan_one's global queues are sized for 1/32 of a frame's windows each; a frame that keeps more alive than that must
     raise the plan's queue flag (PIGO_ERR_CAPACITY from pigo_plan_status), not hang and not drop windows silently -- and the
