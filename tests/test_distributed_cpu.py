@@ -187,3 +187,19 @@ def test_pack_unpack_roundtrip():
     import pytest
     with pytest.raises(ValueError):
         distributed.pack_lists(dets, counts, 16)  # gather_cap larger than the lists' capacity
+
+
+def test_wire_flag_constants_match_the_header():
+    """The Python mirror's WIRE_* bits are the header's PIGO_WIRE_* (include/pigo_hip.h is what a cgo / C++ host binds), and a row
+    is two head words + gather_cap records in both."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "pigo_hip.h")).read()
+    want = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define PIGO_WIRE_(\w+) (\d+)", hdr)}
+    assert want == {"TRUNCATED_GATHER": distributed.WIRE_TRUNCATED_GATHER, "TRUNCATED_DETCAP": distributed.WIRE_TRUNCATED_DETCAP,
+                    "QUEUE_OVERFLOW": distributed.WIRE_QUEUE_OVERFLOW, "WOULD_PANIC": distributed.WIRE_WOULD_PANIC,
+                    "RANK_FAILED": distributed.WIRE_RANK_FAILED, "PADDING": distributed.WIRE_PADDING}, want
+    L = core.load_library()
+    for g in (1, 8, 64):
+        assert int(L.pigo_wire_words(g)) == distributed.WIRE_HEAD + 4 * g
+    assert "pigo_wire_row_flags" in open(os.path.join(root, "include", "pigo.hpp")).read()
