@@ -733,6 +733,12 @@ def main():
                 "achieved": round(alg_bytes / (elapsed / args.steps) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                 "achieved_over_serial_kernel_sum": round(achieved, 2) if achieved else None,
+                # the dominant kernel by itself: k_scan_region's two launches (HIP events, each launch alone on the stream) against the same bytes
+                "dominant_kernel": ({"name": "k_scan_region (small + mid group launches)",
+                                     "ms_per_step": round(ktimes.get("scan_region_small", 0.0) + ktimes.get("scan_region_mid", 0.0), 4),
+                                     "achieved": round(alg_bytes / ((ktimes.get("scan_region_small", 0.0) + ktimes.get("scan_region_mid", 0.0)) * 1e-3) / 1e9, 2),
+                                     "frac": round(alg_bytes / ((ktimes.get("scan_region_small", 0.0) + ktimes.get("scan_region_mid", 0.0)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                                    if ktimes.get("scan_region_small") else None),
                 "traffic": traffic,
                 "traffic_note": tnote,
                 "traffic_source": tsrc,
