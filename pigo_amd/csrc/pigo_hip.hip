@@ -844,8 +844,13 @@ bool build_region_groups(pigo_plan &p)
             else if (has_big) chunks += (nw + kBigChunk - 1) / kBigChunk;
         }
         const int slots = std::max(2, env_int("PIGO_ONE_SLOTS", 256) / p.max_frames);
-        const int nbig = (int)std::min<long long>((chunks + kOneBigWaves - 1) / kOneBigWaves, slots / 2);
-        const double cost0 = (double)w[0], cost1 = (double)w[1] * (env_int("PIGO_ONE_W1_X10", 30) / 10.0);
+        // (PIGO_ONE_BIGMIX, the default: the big-scale chunks are no items of their own -- they ride on the last waves of the region
+        // items, whose scan phase leaves the texture path idle; see k_scan_one)
+        const bool bigmix = env_int("PIGO_ONE_BIGMIX", 1) != 0;
+        const int nbig = bigmix ? 0 : (int)std::min<long long>((chunks + kOneBigWaves - 1) / kOneBigWaves, slots / 2);
+        // (a mid-group window costs about three small-group ones alone; with the big-scale chunks riding on the regions -- the mid
+        // group's first -- 4.5 balances faces, rotated scans and small frames best: r05_experiments.md section 5)
+        const double cost0 = (double)w[0], cost1 = (double)w[1] * (env_int("PIGO_ONE_W1_X10", bigmix ? 45 : 30) / 10.0);
         const int rest = std::max(2, slots - nbig);
         int t1 = w[1] > 0 ? std::max(1, (int)(rest * cost1 / std::max(1.0, cost0 + cost1) + 0.5)) : 0;
         if (w[0] > 0) t1 = std::min(t1, rest - 1);
@@ -1184,7 +1189,13 @@ void build_one(pigo_plan &p)
         }
         B.nh = nh;
         B.one_pti = env_int("PIGO_ONE_PTI", 9);
-        o.nbig = (B.cpf + kOneBigWaves - 1) / kOneBigWaves;
+        o.bigmix = std::max(0, std::min(2, env_int("PIGO_ONE_BIGMIX", 1)));
+        o.regs_per_frame = (uint32_t)(o.grp[0].ncx * o.grp[0].ncy) + (o.ngrp > 1 ? (uint32_t)(o.grp[1].ncx * o.grp[1].ncy) : 0u);
+        // (mixed in, a workgroup's k-th chunk goes to its k-th wave from the top: at most kOneBigWaves / 2 chunks per region item)
+        if (o.bigmix && (uint64_t)o.regs_per_frame * (kOneBigWaves / 2) < B.cpf) o.bigmix = 0;
+        for (int g = 0; g < o.ngrp; ++g)
+            if (o.grp[g].wave_q < kBigChunk) o.bigmix = 0;  // (the chunk's windows live in the wave's own queue)
+        o.nbig = o.bigmix ? 0u : (B.cpf + kOneBigWaves - 1) / kOneBigWaves;
         lds = std::max(lds, (size_t)kOneBigWaves * kBigChunk * 6);
     }
     p.one_lds = lds;
