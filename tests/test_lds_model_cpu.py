@@ -43,3 +43,17 @@ def test_the_committed_microbenchmark_output_agrees_with_the_model_within_5_perc
             meas, model = float(m.group(3)), float(m.group(4))
             assert abs(meas - model) / model < 0.05, line
     assert rows >= 15, rows
+
+
+def test_the_microbenchmarks_compile_for_gfx950(tmp_path):
+    """scripts/micro/*.hip are evidence (profiles/r03_ta_gather.txt, r05_lds_gather.txt): they must keep building with the image's hipcc."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    for name in ("lds_gather", "ta_gather"):
+        src = os.path.join(ROOT, "scripts", "micro", name + ".hip")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", src, "-o", str(tmp_path / name)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
