@@ -101,21 +101,30 @@ struct pigo_cascade {
     DevBuf<float> d_leaf, d_thr;
     DevBuf<int16_t> d_pass_end;          // k_tail_deep: the lane=tree pass that starts at tree t covers trees [t, d_pass_end[t])
     DevBuf<uint2> d_codes_t;             // depth-6 cascades: child-pair table, node-major [32][ntrees] (pigo_cascade_create)
-    std::mutex mu;                       // guards the slot list below and pigo_cluster_detections' scratch
+    std::mutex mu;                       // guards the two slot lists below -- never held across a launch or a synchronisation
     // RunCascade slots: everything one call needs (plan, device + pinned host buffers, a stream, the captured graph of
     // "upload, scan, download").  A call takes a free slot with its parameters (or makes one), so goroutines calling RunCascade on
     // one *Pigo concurrently -- the reference is re-entrant, examples/web/main.go:71,141 -- run next to each other on the GPU.
     struct RunSlot;
     std::list<std::unique_ptr<RunSlot>> slots;   // most recently used first
-    // scratch for pigo_run_cascade / pigo_cluster_detections
-    DevBuf<uint8_t> d_frame;
-    DevBuf<pigo_det> d_dets, d_sorted, d_clusters;
-    DevBuf<int32_t> d_small;             // counts etc.
-    pigo_det *h_cl = nullptr;            // pinned host staging of pigo_cluster_detections' short lists: [in | out | counts]
-    hipStream_t cl_stream = nullptr;
-    DevBuf<int32_t> d_cl_seeds, d_cl_tmpn;   // long lists: k_cluster_seeds / _members / _compact
-    DevBuf<pigo_det> d_cl_tmp;
-    DevBuf<float> d_mq;
+    // ClusterDetections slots: the reference's ClusterDetections is a pure function that goroutines call concurrently on one
+    // *Pigo (examples/web/main.go:141-144), so a call owns its scratch -- pinned staging, a stream, the long lists' device
+    // buffers -- for its duration and N callers run next to each other (and next to RunCascade's slot lookup)
+    struct ClusterSlot {
+        bool busy = false;
+        pigo_det *h_cl = nullptr;        // pinned host staging of the short lists: [in | out | counts]
+        hipStream_t stream = nullptr;
+        DevBuf<pigo_det> d_sorted, d_clusters, d_cl_tmp;
+        DevBuf<int32_t> d_small;         // [0] n, [1] clusters, [2] seeds
+        DevBuf<int32_t> d_cl_seeds, d_cl_tmpn;   // long lists: k_cluster_seeds / _members / _compact
+        DevBuf<float> d_mq;
+        ~ClusterSlot()
+        {
+            if (stream) (void)hipStreamDestroy(stream);
+            if (h_cl) (void)hipHostFree(h_cl);
+        }
+    };
+    std::list<std::unique_ptr<ClusterSlot>> cl_slots;
 };
 
 struct PlanKey {
@@ -432,8 +441,7 @@ extern "C" void pigo_cascade_destroy(pigo_cascade *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->cl_stream) (void)hipStreamDestroy(c->cl_stream);
-    if (c->h_cl) (void)hipHostFree(c->h_cl);
+    c->cl_slots.clear();
     delete c;
 }
 
@@ -1763,7 +1771,10 @@ void launch_scan(const pigo_plan &p, const ScanArgs &a, int variant, hipStream_t
             (void)hipMemsetAsync(p.d_onecnt.p, 0, (size_t)kOneCntWords * 4, s);
         }
         mark("scan_one");
-        k_scan_one<ROT><<<std::min<uint32_t>(o.nitems, (uint32_t)p.one_grid), kRegThreads, p.one_lds, s>>>(oa, o);
+        // At least eight workgroups: producers spread their survivors over all eight queues (one_push) and a workgroup only drains
+        // queue blockIdx & 7 (one_consume) -- a small frame has fewer than eight items (30 x 40 px: ~6 regions), and with a grid of
+        // nitems nobody would take what lands in the queues beyond it.  A workgroup that finds no item consumes at once.
+        k_scan_one<ROT><<<std::max<uint32_t>(8u, std::min<uint32_t>(o.nitems, (uint32_t)p.one_grid)), kRegThreads, p.one_lds, s>>>(oa, o);
     } else if (variant == 2 || variant == 3) {
         const bool v3 = variant == 3;
         const long long qtotal = p.qcap * (long long)p.max_frames;  // entries of d_queue
@@ -2277,23 +2288,47 @@ extern "C" pigo_status pigo_cluster_detections(pigo_cascade *c, pigo_det *dets, 
     if (n < 0 || (n > 0 && !dets)) return fail(PIGO_ERR_PARAM, "bad detection list");
     if (n == 0) return PIGO_OK;  // clusters := []Detection{}  (pigo.go:280)
     pigo_sort_by_q(dets, n);     // pigo.go:264-266, in place like the reference
-    std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    // a free slot, or a new one: the handle's lock covers the list only (N concurrent callers = N slots, each with its own stream)
+    pigo_cascade::ClusterSlot *sl = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        for (auto &u : c->cl_slots)
+            if (!u->busy) {
+                sl = u.get();
+                break;
+            }
+        if (!sl) {
+            std::unique_ptr<pigo_cascade::ClusterSlot> u(new (std::nothrow) pigo_cascade::ClusterSlot);
+            if (!u) return fail(PIGO_ERR_NOMEM, "out of memory");
+            sl = u.get();
+            c->cl_slots.push_back(std::move(u));
+        }
+        sl->busy = true;
+    }
+    struct Release {
+        pigo_cascade *c;
+        pigo_cascade::ClusterSlot *sl;
+        ~Release()
+        {
+            std::lock_guard<std::mutex> lock(c->mu);
+            sl->busy = false;
+        }
+    } release{c, sl};
+    if (!sl->stream) HIP_TRY(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));
+    hipStream_t s = sl->stream;
     if (n <= kClusterStaged && env_int("PIGO_CLUSTER_V2", -1) < 0) {
         // a short list (what one frame yields): ONE launch that reads the sorted list from pinned host memory into LDS and writes the
         // clusters and their number back to pinned host memory, one synchronisation -- no copy in front of or behind the kernel
-        if (!c->h_cl) {
-            HIP_TRY(hipHostMalloc((void **)&c->h_cl, (size_t)kClusterStaged * sizeof(pigo_det) * 2 + 64, hipHostMallocDefault));
-            HIP_TRY(hipStreamCreateWithFlags(&c->cl_stream, hipStreamNonBlocking));
-        }
-        pigo_det *h_in = c->h_cl, *h_out = c->h_cl + kClusterStaged;
-        int32_t *h_cnt = reinterpret_cast<int32_t *>(c->h_cl + 2 * kClusterStaged);  // [0] n, [1] clusters
+        if (!sl->h_cl) HIP_TRY(hipHostMalloc((void **)&sl->h_cl, (size_t)kClusterStaged * sizeof(pigo_det) * 2 + 64, hipHostMallocDefault));
+        pigo_det *h_in = sl->h_cl, *h_out = sl->h_cl + kClusterStaged;
+        int32_t *h_cnt = reinterpret_cast<int32_t *>(sl->h_cl + 2 * kClusterStaged);  // [0] n, [1] clusters
         memcpy(h_in, dets, (size_t)n * sizeof(pigo_det));
         h_cnt[0] = n;
         h_cnt[1] = -1;
-        k_cluster<256, true><<<1, 256, 0, c->cl_stream>>>(h_in, h_cnt, kClusterStaged, iou_threshold, h_out, h_cnt + 1, nullptr);
+        k_cluster<256, true><<<1, 256, 0, s>>>(h_in, h_cnt, kClusterStaged, iou_threshold, h_out, h_cnt + 1, nullptr);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(c->cl_stream));
+        HIP_TRY(hipStreamSynchronize(s));
         const int32_t ncl = h_cnt[1];
         if (ncl < 0) return fail(PIGO_ERR_HIP, "ClusterDetections: the kernel left no result");
         if (n_out) *n_out = ncl;
@@ -2304,37 +2339,44 @@ extern "C" pigo_status pigo_cluster_detections(pigo_cascade *c, pigo_det *dets, 
         }
         return PIGO_OK;
     }
-    if (c->d_sorted.n < (size_t)n) HIP_TRY(c->d_sorted.alloc(n));
-    if (c->d_clusters.n < (size_t)n) HIP_TRY(c->d_clusters.alloc(n));
-    if (c->d_mq.n < (size_t)n) HIP_TRY(c->d_mq.alloc(n));
-    if (c->d_small.n < 4) HIP_TRY(c->d_small.alloc(4));
+    if (sl->d_sorted.n < (size_t)n) HIP_TRY(sl->d_sorted.alloc(n));
+    if (sl->d_clusters.n < (size_t)n) HIP_TRY(sl->d_clusters.alloc(n));
+    if (sl->d_mq.n < (size_t)n) HIP_TRY(sl->d_mq.alloc(n));
+    if (sl->d_small.n < 4) HIP_TRY(sl->d_small.alloc(4));
     const int32_t h_small[2] = {n, 0};
-    HIP_TRY(hipMemcpy(c->d_small.p, h_small, 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_sorted.p, dets, (size_t)n * sizeof(pigo_det), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(sl->d_small.p, h_small, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(sl->d_sorted.p, dets, (size_t)n * sizeof(pigo_det), hipMemcpyHostToDevice, s));
     const int mode = env_int("PIGO_CLUSTER_V2", -1);
     if (mode >= 0 ? mode != 0 : n > 2048) {  // long list: seeds first, then every cluster on its own wave (no length limit)
-        if (c->d_cl_seeds.n < (size_t)n) HIP_TRY(c->d_cl_seeds.alloc(n));
-        if (c->d_cl_tmpn.n < (size_t)n) HIP_TRY(c->d_cl_tmpn.alloc(n));
-        if (c->d_cl_tmp.n < (size_t)n) HIP_TRY(c->d_cl_tmp.alloc(n));
-        k_cluster_seeds<<<1, kSeedThreads>>>(c->d_sorted.p, c->d_small.p, n, iou_threshold, c->d_cl_seeds.p, c->d_small.p + 2);
-        k_cluster_members<<<dim3((unsigned)std::max(1, std::min((n + 3) / 4, 2048)), 1u), kMemberThreads>>>(c->d_sorted.p, c->d_small.p, n, iou_threshold, c->d_cl_seeds.p,
-                                                                                                              c->d_small.p + 2, c->d_cl_tmp.p, c->d_cl_tmpn.p);
-        k_cluster_compact<<<1, 256>>>(c->d_small.p + 2, n, c->d_cl_tmp.p, c->d_cl_tmpn.p, c->d_clusters.p, c->d_small.p + 1);
+        if (sl->d_cl_seeds.n < (size_t)n) HIP_TRY(sl->d_cl_seeds.alloc(n));
+        if (sl->d_cl_tmpn.n < (size_t)n) HIP_TRY(sl->d_cl_tmpn.alloc(n));
+        if (sl->d_cl_tmp.n < (size_t)n) HIP_TRY(sl->d_cl_tmp.alloc(n));
+        k_cluster_seeds<<<1, kSeedThreads, 0, s>>>(sl->d_sorted.p, sl->d_small.p, n, iou_threshold, sl->d_cl_seeds.p, sl->d_small.p + 2);
+        k_cluster_members<<<dim3((unsigned)std::max(1, std::min((n + 3) / 4, 2048)), 1u), kMemberThreads, 0, s>>>(sl->d_sorted.p, sl->d_small.p, n, iou_threshold,
+                                                                                                                    sl->d_cl_seeds.p, sl->d_small.p + 2, sl->d_cl_tmp.p,
+                                                                                                                    sl->d_cl_tmpn.p);
+        k_cluster_compact<<<1, 256, 0, s>>>(sl->d_small.p + 2, n, sl->d_cl_tmp.p, sl->d_cl_tmpn.p, sl->d_clusters.p, sl->d_small.p + 1);
     } else if (n <= 256 * 64) {
-        k_cluster<256><<<1, 256>>>(c->d_sorted.p, c->d_small.p, n, iou_threshold, c->d_clusters.p, c->d_small.p + 1, c->d_mq.p);
+        k_cluster<256><<<1, 256, 0, s>>>(sl->d_sorted.p, sl->d_small.p, n, iou_threshold, sl->d_clusters.p, sl->d_small.p + 1, sl->d_mq.p);
     } else if (n <= 65536) {
-        k_cluster<1024><<<1, 1024>>>(c->d_sorted.p, c->d_small.p, n, iou_threshold, c->d_clusters.p, c->d_small.p + 1, c->d_mq.p);
+        k_cluster<1024><<<1, 1024, 0, s>>>(sl->d_sorted.p, sl->d_small.p, n, iou_threshold, sl->d_clusters.p, sl->d_small.p + 1, sl->d_mq.p);
     } else {
+        (void)hipStreamSynchronize(s);  // (the uploads read the caller's memory)
         return fail(PIGO_ERR_PARAM, "k_cluster supports at most 65536 detections (PIGO_CLUSTER_V2=0 was forced)");
     }
-    HIP_TRY(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) {
+        (void)hipStreamSynchronize(s);
+        return fail(PIGO_ERR_HIP, "ClusterDetections: a launch failed");
+    }
     int32_t ncl = 0;
-    HIP_TRY(hipMemcpy(&ncl, c->d_small.p + 1, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(&ncl, sl->d_small.p + 1, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     if (n_out) *n_out = ncl;
     if (ncl > cap) return fail(PIGO_ERR_CAPACITY, "ClusterDetections: %d clusters, capacity %d", ncl, cap);
     if (ncl > 0) {
         if (!out) return fail(PIGO_ERR_PARAM, "out is NULL");
-        HIP_TRY(hipMemcpy(out, c->d_clusters.p, (size_t)ncl * sizeof(pigo_det), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(out, sl->d_clusters.p, (size_t)ncl * sizeof(pigo_det), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
     }
     return PIGO_OK;
 }
@@ -2845,7 +2887,7 @@ struct pigo_comm {
     int rank = 0, world = 1, device = 0;
     rccl_comm_t comm = nullptr;  // NULL when world == 1: nothing to exchange
     bool aborted = false;        // pigo_comm_abort was called: every further collective on it is refused
-    std::mutex mu;               // comm / aborted: pigo_comm_abort may come from another thread than the one enqueueing collectives
+    std::mutex mu;               // comm / aborted (the two words only, never held across an RCCL call): pigo_comm_abort may come from another thread
 };
 
 extern "C" pigo_status pigo_comm_unique_id(uint8_t id[PIGO_COMM_ID_BYTES])
@@ -2934,13 +2976,21 @@ extern "C" pigo_status pigo_comm_init(const uint8_t id[PIGO_COMM_ID_BYTES], int 
 extern "C" pigo_status pigo_comm_abort(pigo_comm *c)
 {
     if (!c) return fail(PIGO_ERR_PARAM, "comm is NULL");
-    std::lock_guard<std::mutex> lock(c->mu);
-    if (!c->comm) return PIGO_OK;  // world 1 without an id: nothing in flight
-    if (!g_rccl.abort) return fail(PIGO_ERR_HIP, "librccl has no ncclCommAbort");
+    // The lock only covers the handle's two words.  ncclCommAbort itself runs WITHOUT it: it is what a host calls while another
+    // thread sits inside an ncclAllGather enqueue that blocks on the host (lazy connection setup of the first collective, a full
+    // proxy queue, a dead peer) -- that thread does not hold the lock either (pigo_run_batch_sharded), and ncclCommAbort is made to
+    // run next to a stuck collective, which then returns an error to its caller.
+    rccl_comm_t h = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        if (!c->comm) return PIGO_OK;  // world 1 without an id: nothing in flight (or aborted already)
+        if (!g_rccl.abort) return fail(PIGO_ERR_HIP, "librccl has no ncclCommAbort");
+        h = c->comm;
+        c->comm = nullptr;
+        c->aborted = true;
+    }
     (void)hipSetDevice(c->device);
-    const int rc = g_rccl.abort(c->comm);
-    c->comm = nullptr;
-    c->aborted = true;
+    const int rc = g_rccl.abort(h);
     if (rc != 0) return fail(PIGO_ERR_HIP, "ncclCommAbort: %s", g_rccl.err ? g_rccl.err(rc) : "rccl error");
     return PIGO_OK;
 }
@@ -3075,14 +3125,20 @@ extern "C" pigo_status pigo_run_batch_sharded(pigo_plan *p, pigo_comm *comm, con
         k_pack_lists<<<frames_per_rank, 256, 0, s>>>(p->sh_dets.p, d_counts, nullptr, nullptr, 0, p->det_cap, gather_cap, 1, p->sh_wire.p);
         if (hipGetLastError() != hipSuccess) (void)hipMemsetAsync(p->sh_wire.p, 0, row_words * 4, s);
     }
-    std::unique_lock<std::mutex> comm_lock;
-    if (comm) comm_lock = std::unique_lock<std::mutex>(comm->mu);  // (the enqueue, not the collective: pigo_comm_abort gets its turn right after)
-    if (comm && comm->aborted) return fail(PIGO_ERR_PARAM, "the communicator was aborted (pigo_comm_abort) while this call was preparing its rows");
-    if (comm && comm->comm) {
+    // The handle is read under the communicator's lock, the enqueue runs without it: an RCCL enqueue can block on the host, and
+    // pigo_comm_abort -- which exists for exactly that state -- must be able to run from another thread (it then makes this call
+    // return with RCCL's error).
+    rccl_comm_t handle = nullptr;
+    if (comm) {
+        std::lock_guard<std::mutex> lock(comm->mu);
+        if (comm->aborted) return fail(PIGO_ERR_PARAM, "the communicator was aborted (pigo_comm_abort) while this call was preparing its rows");
+        handle = comm->comm;
+    }
+    if (handle) {
         const Rccl *r = nullptr;
         const pigo_status rs = rccl_load(&r);
         if (rs != PIGO_OK) return rs;
-        RCCL_TRY(r, r->all_gather(p->sh_wire.p, d_gathered, row_words, kNcclInt32, comm->comm, s));
+        RCCL_TRY(r, r->all_gather(p->sh_wire.p, d_gathered, row_words, kNcclInt32, handle, s));
     } else {
         if (world > 1) return fail(PIGO_ERR_PARAM, "communicator of %d ranks without an RCCL handle", world);
         HIP_TRY(hipMemcpyAsync(d_gathered + (size_t)rank * row_words, p->sh_wire.p, row_words * 4, hipMemcpyDeviceToDevice, s));

@@ -892,6 +892,45 @@ def test_run_cascade_is_reentrant_four_threads_one_handle(orc, graph, monkeypatc
     assert not errors, errors
 
 
+def test_cluster_detections_is_reentrant_four_threads_one_handle(orc):
+    """The reference's ClusterDetections is a pure function (core/pigo.go:262-308) that goroutines call concurrently on one
+    *Pigo (examples/web/main.go:141-144).  Until round 5 pigo_cluster_detections held the handle's mutex across its launch and
+    synchronisation; now a call owns a slot (pinned staging, stream, device scratch) and the mutex covers the slot list only.
+    Four threads, one handle, lists of every path's length (one-launch pinned path, k_cluster on the device, seeds / members /
+    compact), each thread's results against the oracle's, next to threads that call RunCascade on the same handle."""
+    import threading
+    fresh = core.NewPigo(0).Unpack(synth.facefinder_bytes())
+    rng = np.random.default_rng(99)
+
+    def boxes(n, spread):
+        return [(int(rng.integers(50, spread)), int(rng.integers(50, spread)), int(rng.integers(20, 120)), np.float32(rng.random() * 30 + 0.01 * i)) for i in range(n)]
+
+    lists = [boxes(40, 600), boxes(700, 1500), boxes(1500, 3000), boxes(3000, 4000), boxes(9, 200)]
+    ious = [0.0, 0.1, 0.2, 0.15, 0.01]
+    wants = [orc.cluster_detections(oracle.make_dets(l), iou) for l, iou in zip(lists, ious)]
+    img = synth.syn_faces(240, 320, seed=11)
+    want_scan = orc.run_cascade(img, 240, 320, 320, 20, 1000, 0.1, 1.1, 0.0)
+    errors = []
+
+    def work(k):
+        try:
+            for rep in range(12):
+                j = (k + rep) % len(lists)
+                got = fresh.ClusterDetections(core.make_dets(lists[j]), ious[j])
+                assert_same_dets(got, wants[j], f"thread {k} rep {rep} list {j}", Q_TOL_RAW)
+                if k == 3:
+                    assert_same_dets(fresh.RunCascade(_cp(img, 240, 320, 320, 20, 1000, 0.1, 1.1), 0.0), want_scan, f"RunCascade next to clustering, rep {rep}", Q_TOL_RAW)
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {k}: {e!r}")
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+
+
 def test_one_frame_plans_in_a_process_full_of_streams(pg, orc):
     """A process's HIP streams share a handful of hardware queues.  Until round 4 a plan of a few frames forked onto a side
     stream of its own and had to probe it against the caller's; now such a plan is ONE launch on the caller's stream
@@ -972,6 +1011,41 @@ def test_one_launch_plans_hand_off_under_uneven_load(pg, orc, nframes, angle, ki
         assert torch.equal(counts, ref_c) and torch.equal(dets, ref_d), f"launch {i} next to a busy batch plan differs from the first"
     torch.cuda.synchronize()
     big.status()
+
+
+def _small_face(f, crop=None):
+    """The sample face shrunk by the integer factor f (box average), optionally cropped: faces of scale ~24...40 in frames of a
+    few regions."""
+    g = synth.sample_gray()
+    H, W = (400 // f) * f, (320 // f) * f
+    im = g[:H, :W].reshape(H // f, f, W // f, f).mean(axis=(1, 3)).round().astype(np.uint8)
+    if crop is not None:
+        im = im[crop[0]:crop[1], crop[2]:crop[3]]
+    return np.ascontiguousarray(im)
+
+
+@pytest.mark.parametrize("angle", [0.0, 0.03])
+def test_one_launch_plan_on_frames_of_fewer_than_eight_items(orc, angle):
+    """A frame of a few dozen pixels is fewer than eight items for k_scan_one, whose producers spread survivors over all eight
+    global queues while a workgroup only drains queue blockIdx & 7: with a grid of `nitems` workgroups the faces whose windows
+    landed in the queues beyond it were dropped without a word, and their entries stayed behind for the plan's next run (advisor,
+    round 5).  The launch has at least eight workgroups now.  Every frame is scanned twice through one handle (the second run
+    starts from whatever the first left in the queues), min size 16 so that the small faces are inside the ladder;
+    core/pigo.go:212-258."""
+    fresh = core.NewPigo(0).Unpack(synth.facefinder_bytes())
+    total = 0
+    for f, crop, shift in ((10, None, 0.05), (10, (2, 34, 0, 32), 0.1), (9, (4, 44, 0, 32), 0.05), (8, None, 0.1), (9, None, 0.05), (6, None, 0.05)):
+        im = _small_face(f, crop)
+        rows, cols = im.shape
+        dim = (cols + 3) & ~3
+        buf = np.full((rows, dim), 128, dtype=np.uint8)
+        buf[:, :cols] = im
+        want = orc.run_cascade(buf, rows, cols, dim, 16, 1000, shift, 1.1, angle)
+        for rep in range(2):
+            got = fresh.RunCascade(_cp(buf, rows, cols, dim, 16, 1000, shift, 1.1), angle)
+            assert_same_dets(got, want, f"{rows}x{cols} (dim {dim}) shift {shift} angle {angle}, run {rep}", Q_TOL_RAW)
+        total += len(want)
+    assert total > 100 or angle > 0.0
 
 
 def test_one_launch_plan_with_a_list_too_long_for_its_own_order_restore(pg, orc):
