@@ -835,7 +835,9 @@ bool build_region_groups(pigo_plan &p)
     p.side_lds = reserve_g[0];
     const size_t max_dyn_all = (size_t)(160 << 10) - 3072;
     // (group limits: 51 / 148 measured best after the deep list got cheaper -- 42…51 / 148 within 0.3 %, 62 / 135 3 % slower)
-    const int smax[NG] = {env_int("PIGO_REG_S0", 51), env_int("PIGO_REG_S1", 148), 0};
+    // (no rung beyond s = 255 in a region group: the pool and the deep lists compute a window's offsets in packed 16-bit arithmetic,
+    // |code * s| <= 128 * 255 -- fly_points_pk)
+    const int smax[NG] = {std::min(255, env_int("PIGO_REG_S0", 51)), std::min(255, env_int("PIGO_REG_S1", 148)), 0};
     const int cwmax[NG] = {env_int("PIGO_REG_CW0", 320), env_int("PIGO_REG_CW1", 192), env_int("PIGO_REG_CW2", 128)};
     int k = 0;
     const int nscales = (int)p.scales.size();

@@ -9,7 +9,7 @@
 //          walk's own ~8: if the pipes overlapped, time would stay flat in K until the VALU became the longer pipe;
 //   PAT    the pixel reads' address pattern: coherent (every lane at the same node: 2.5 LDS cycles per read) or divergent (each
 //          lane at its own node, offsets uniform in +-R: ~6.9 cycles): the same VALU work over a cheap and an expensive LDS side;
-//   MODE   the schedule inside a wave: 0 lock step (all loads of a level, then all arithmetic -- rounds 1-4), 1 two half-batches
+//   MODE   the schedule inside a wave (3: the child's entry loaded AFTER the compare, see there): 0 lock step (all loads of a level, then all arithmetic -- rounds 1-4), 1 two half-batches
 //          half a level apart (round 5's reg_walk), 2 a rotation window by window (retire window n, issue its next level at once:
 //          the wave never has fewer than N-1 windows' loads in flight);
 //   waves  16 / 12 / 8 per CU (4, 3, 2 per SIMD) and N = 8 / 4 windows per lane.
@@ -145,6 +145,32 @@ __global__ __launch_bounds__(1024) void k_mix(const uint8_t *__restrict__ pix, c
             level(std::integral_constant<int, 3>{});
             level(std::integral_constant<int, 4>{});
             level(std::integral_constant<int, 5>{});
+        } else if constexpr (MODE == 3) {
+            // dependent entry load: the compare's bit goes into the node index through the carry (idx = 2 idx + bit, ONE v_addc), the
+            // child's 4-byte entry is loaded AFTER the compare -- two LDS round trips per level, but 5 instead of 6 VALU instructions
+            // per window-level (no select of the pair's halves) and a 4-byte instead of an 8-byte table read
+            uint32_t idx[N];
+#pragma unroll
+            for (int n = 0; n < N; ++n) idx[n] = 1u;
+#pragma unroll
+            for (int l = 0; l < 6; ++l) {
+#pragma unroll
+                for (int n = 0; n < N; ++n) {
+                    const int d1 = (int)(short)(e[n] & 0xffffu), d2 = ((int)e[n]) >> 16;
+                    p1[n] = *(lds_u8)(size_t)(uint32_t)((int)base[n] + d1);
+                    p2[n] = *(lds_u8)(size_t)(uint32_t)((int)base[n] + d2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < N; ++n) {
+                    // idx = 2 idx + (p1 <= p2): the compare's bit enters through the carry (the compiler selects 0 / 1 and adds)
+                    asm("v_cmp_le_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(idx[n]) : "v"(p1[n]), "v"(p2[n]) : "vcc");
+                    if (l < 5) e[n] = *(lds_u32)(size_t)(tb + idx[n] * 4u);
+                    else x[n] += idx[n];
+                    extra_valu<K>(x[n], e[n]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
             // rotation: window n's level l is retired and its level l + 1 issued at once -- the other N - 1 windows' loads are in flight
             issue(I0{}, I0{}, IN{});
@@ -260,6 +286,7 @@ int main(int argc, char **argv)
         row<8, 0>(r, name, 1024);
         row<8, 1>(r, name, 1024);
         row<8, 2>(r, name, 1024);
+        row<8, 3>(r, name, 1024);
         row<4, 0>(r, name, 1024);
         row<4, 2>(r, name, 1024);
         row<8, 1>(r, name, 768);
