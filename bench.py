@@ -277,7 +277,12 @@ def config_leg(args, pg, dev, what, frames_n, steps, verify_k, **over):
                        f", MinSize={a2.min_size} MaxSize={a2.max_size} Shift={a2.shift} Scale={a2.scale} angle={a2.angle}, {frames_n} HBM-resident frames per step",
            "frames": frames_n, "steps": steps, "ms_per_step": round(ms, 4), "windows_per_frame": wpf, "variant": int(info.variant),
            "mwindows_per_s": round(frames_n * wpf / ms / 1e3, 1), "frames_per_s": round(frames_n / ms * 1e3, 1),
-           "detections": int(counts.sum().item()), "clusters": int(cl[2].sum().item()), "verified_frames": checked}
+           "detections": int(counts.sum().item()), "clusters": int(cl[2].sum().item()), "verified_frames": checked,
+           "verified": ("every frame of the leg's batch" if len(checked) == frames_n else f"{len(checked)} of {frames_n} frames") + " vs the CPU oracle, raw lists and clusters bit-exact",
+           # the same definition as the headline's roofline: every frame read once + 16 B per emitted detection, over the timed step
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "algorithmic_bytes_per_window": round(a2.rows * a2.cols / wpf, 4),
+                        "achieved": round((frames_n * a2.rows * a2.cols + 16 * int(counts.sum().item())) / (ms * 1e-3) / 1e9, 2),
+                        "frac": round((frames_n * a2.rows * a2.cols + 16 * int(counts.sum().item())) / (ms * 1e-3) / 1e9 / 8000.0, 5), "traffic": None}}
     del plan, d_fr, dets, counts, cl
     return leg
 
@@ -637,12 +642,12 @@ def main():
         assert torch.equal(cntS[:B], counts) and torch.equal(detS[:B], dets), "the shard's first frames must reproduce the default batch"
         shard_checked = []
         if args.verify_frames > 0:  # frames only the shard has (its last ones), against the CPU oracle
-            tail = S - 4
-            shard_checked = [tail + j for j in verify_against_oracle(args, fS[tail:], detS[tail:], cntS[tail:], clS[1][tail:], clS[2][tail:], 4, what="config-3 shard tail")]
+            tail = S - 16
+            shard_checked = [tail + j for j in verify_against_oracle(args, fS[tail:], detS[tail:], cntS[tail:], clS[1][tail:], clS[2][tail:], 16, what="config-3 shard tail")]
         shard_leg = {"frames_per_gpu": S, "ms_per_step": round(msS, 3), "mwindows_per_s": round(S * int(info.windows_per_frame) / msS / 1e3, 1),
                      "frames_per_s": round(S / msS * 1e3, 1), "resident_bytes": int(fS.nbytes), "detections": int(cntS.sum().item()),
                      "verified_frames": shard_checked,
-                     "note": "BASELINE configs[2] per-GPU shard (8192 frames / 8 GPUs); its first frames compared with the default batch, its last four with the CPU oracle"}
+                     "note": "BASELINE configs[2] per-GPU shard (8192 frames / 8 GPUs); its first frames compared with the default batch, its last sixteen with the CPU oracle"}
         del planS, dS, detS, cntS, clS, fS
 
     # ---- BASELINE configs[3] (rotated scan, angle 0.8: on the benchmark's upright faces and on faces rotated the way that scan
@@ -650,10 +655,11 @@ def main():
     config4_leg = config5_leg = ref_leg = None
     default_cfg = (args.rows, args.cols, args.angle, args.kind, args.face_rotation) == (1080, 1920, 0.0, "faces", 0.0)
     if side_legs and default_cfg and not args.no_config_legs:
-        vk = 2 if args.verify_frames > 0 else 0
-        config4_leg = {"upright_faces": config_leg(args, pg, dev, "config-4 leg (upright faces)", 64, 5, vk, angle=0.8),
-                       "rotated_faces": config_leg(args, pg, dev, "config-4 leg (rotated faces)", 64, 5, vk, angle=0.8, face_rotation=-79.0)}
-        config5_leg = config_leg(args, pg, dev, "config-5 leg (4K)", 8, 3, vk, rows=2160, cols=3840, min_size=20, max_size=2000, shift=0.05,
+        # (every frame of these legs is checked against the CPU oracle: 64 + 64 1080p frames and 8 4K frames, one host thread each)
+        vall = args.verify_frames > 0
+        config4_leg = {"upright_faces": config_leg(args, pg, dev, "config-4 leg (upright faces)", 64, 5, 64 if vall else 0, angle=0.8),
+                       "rotated_faces": config_leg(args, pg, dev, "config-4 leg (rotated faces)", 64, 5, 64 if vall else 0, angle=0.8, face_rotation=-79.0)}
+        config5_leg = config_leg(args, pg, dev, "config-5 leg (4K)", 8, 3, 8 if vall else 0, rows=2160, cols=3840, min_size=20, max_size=2000, shift=0.05,
                                  scale=1.05, det_cap=32768)
         ref_leg = reference_benchmark_leg(args, pg)
 
@@ -672,9 +678,9 @@ def main():
         # (separate rocprofv3 --pmc passes, profiles/rNN_traffic.json) gives FABRIC-side bytes per frame -- what the L2s missed,
         # Infinity-Cache hits included -- scaled here to this batch.  It is an upper bound of the HBM bytes.
         traffic, tnote, tsrc = None, None, None
-        tname = {3: "r05_traffic.json", 2: "r01_traffic.json"}.get(int(info.variant))
+        tname = {3: "r06_traffic.json", 2: "r01_traffic.json"}.get(int(info.variant))
         tpath = os.path.join(ROOT, "profiles", tname) if tname else None
-        for older in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
+        for older in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
             if tpath and not os.path.exists(tpath) and int(info.variant) == 3:
                 tname = older
                 tpath = os.path.join(ROOT, "profiles", tname)

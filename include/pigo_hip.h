@@ -37,6 +37,10 @@ typedef int pigo_status;
 #define PIGO_ERR_CAPACITY (-4) /* output buffer too small; *n_out holds the required element count */
 #define PIGO_ERR_PANIC (-5)    /* the reference would panic: pixel index out of range (rotated scan, quirk Q1) */
 #define PIGO_ERR_NOMEM (-6)
+#define PIGO_ERR_TIMEOUT (-7)  /* pigo_plan_status: a wave of a one-launch scan (plans of fewer than 8 frames) waited longer than
+                                  PIGO_ONE_TIMEOUT_MS (default 2000) for a window another workgroup had claimed -- the device was
+                                  taken away from the launch for that long (another process, a debugger).  That run's lists are
+                                  incomplete: run the plan again.  pigo_run_cascade does so by itself. */
 
 /* Detection, core/pigo.go:195-200.  16-byte wire/GPU record; the Go shim widens it to Go's
  * {Row, Col, Scale int; Q float32}. */

@@ -27,7 +27,7 @@ DET_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("scale", "<i4"), ("q", "<
 #: how RgbToGrayscale reads the 4-byte pixels: *image.NRGBA, *image.RGBA, the wasm canvas formula (include/pigo_hip.h)
 PIX_NRGBA, PIX_RGBA, PIX_CANVAS = 0, 1, 2
 
-PIGO_OK, ERR_PACKET, ERR_PARAM, ERR_HIP, ERR_CAPACITY, ERR_PANIC, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
+PIGO_OK, ERR_PACKET, ERR_PARAM, ERR_HIP, ERR_CAPACITY, ERR_PANIC, ERR_NOMEM, ERR_TIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7
 
 
 class PigoPanic(RuntimeError):

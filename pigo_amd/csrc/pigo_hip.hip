@@ -1213,6 +1213,8 @@ void build_one(pigo_plan &p)
     o.nt_late = std::max(1, std::min(4, env_int("PIGO_ONE_NT_LATE", 4)));
     o.late_items = std::max(0, env_int("PIGO_ONE_LATE_ITEMS", 8));
     o.plain_zero = env_int("PIGO_ONE_PLAINZERO", 0);
+    // (a user switch, always honoured: how long a consumer of the one-launch scan waits for a claimed slot before the run is given up)
+    o.wait_ticks = (long long)std::max(1, std::min(600000, env_int("PIGO_ONE_TIMEOUT_MS", 2000))) * 100000LL;
     o.restore = (p.det_cap <= kOneRestoreMax && (size_t)p.det_cap * 4 <= lds && env_int("PIGO_ONE_RESTORE", 1) != 0) ? 1 : 0;
     // queues: room for 1/32 of the windows of the plan's frames in each of the eight (what passes tree 4 of the big rungs, 13 / 28
     // of the groups: well below 1 % on faces and on noise); an overflow raises the queue flag like every survivor queue
@@ -1230,7 +1232,7 @@ void build_one(pigo_plan &p)
 
 // Environment switches.  A handful are for users and always honoured: PIGO_SCAN_VARIANT (force a scan implementation),
 // PIGO_QUEUE_MIN (survivor-queue capacity), PIGO_GRAPH_FRAMES (graph replay of small batches / RunCascade slots),
-// PIGO_COMM_INIT_TIMEOUT_S, PIGO_RCCL_LIB, PIGO_SYNC_DEBUG, PIGO_DEBUG_STATS (debug build).  Everything else is a TUNING switch
+// PIGO_ONE_TIMEOUT_MS (patience of the one-launch scan's hand-offs), PIGO_COMM_INIT_TIMEOUT_S, PIGO_RCCL_LIB, PIGO_SYNC_DEBUG, PIGO_DEBUG_STATS (debug build).  Everything else is a TUNING switch
 // of the A/B scripts and the parity suite (schedule constants, forced code paths, timing experiments) and is ignored unless
 // PIGO_TUNING=1 is set as well -- a production process cannot wander onto a path nobody benchmarks by inheriting a stray variable.
 bool tuning_enabled()
@@ -1246,7 +1248,8 @@ const char *tune_env(const char *name)
 
 int env_int(const char *name, int dflt)
 {
-    static const char *const user[] = {"PIGO_SCAN_VARIANT", "PIGO_QUEUE_MIN", "PIGO_GRAPH_FRAMES", "PIGO_COMM_INIT_TIMEOUT_S", "PIGO_SYNC_DEBUG", "PIGO_DEBUG_STATS"};
+    static const char *const user[] = {"PIGO_SCAN_VARIANT", "PIGO_QUEUE_MIN", "PIGO_GRAPH_FRAMES", "PIGO_COMM_INIT_TIMEOUT_S", "PIGO_SYNC_DEBUG", "PIGO_DEBUG_STATS",
+                                       "PIGO_ONE_TIMEOUT_MS"};
     bool is_user = false;
     for (const char *u : user) is_user = is_user || strcmp(u, name) == 0;
     if (!is_user && !tuning_enabled()) return dflt;
@@ -2097,7 +2100,7 @@ extern "C" pigo_status pigo_plan_status(pigo_plan *p)
     p->last_flags[2] = flags[2];
     if (flags[1]) return fail(PIGO_ERR_PANIC, "the reference would panic: pixel index out of range in classifyRotatedRegion (pigo.go:167-179)");
     if ((flags[0] & 16) && p->one_ok)
-        return fail(PIGO_ERR_CAPACITY,
+        return fail(PIGO_ERR_TIMEOUT,
                     "hand-off timeout inside k_scan_one (queue %u slot %u, workgroup %u: done at claim %u, now %u / %u of %u items; alloc %u / %u, head %u; tags %08x %08x)",
                     rep[0], rep[1], rep[11], rep[2], rep[3], rep[4], rep[8], rep[5], rep[6], rep[7], rep[9], rep[10]);
     if (flags[0])

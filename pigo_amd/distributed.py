@@ -161,12 +161,21 @@ def row_flags(wire):
     return w[:, 1].copy()
 
 
-def allgather_lists(dets, counts, gather_cap: int, frames_per_rank: int, group=None):
-    """All-gather every rank's per-frame lists.  Every rank must pass exactly `frames_per_rank` frames'
-    worth of rows (pad short shards with zero-count frames).  Returns int32 [world*frames_per_rank, 2+4*gather_cap]."""
+def allgather_lists(dets, counts, gather_cap: int, frames_per_rank: int, group=None, raw_counts=None, plan_flags=None, rank_failed=False):
+    """All-gather every rank's per-frame lists over ``torch.distributed``.  Every rank must pass exactly `frames_per_rank` frames'
+    worth of rows (pad short shards with zero-count frames).  Returns int32 [world*frames_per_rank, 2+4*gather_cap].
+
+    The rows carry the same flags word as the C ABI's (pigo_run_batch_sharded packs it on the device): pass ``raw_counts`` (the
+    RunCascade counts a clustered list was made from: TRUNCATED_DETCAP when the RAW list was cut), ``plan_flags`` (``plan.last_flags()``
+    after the scan has been synchronised: QUEUE_OVERFLOW, WOULD_PANIC) and ``rank_failed=True`` when this rank's scan was refused
+    and its rows are padding -- a peer then reads from the rows what it would read from the C ABI's.  Without them the flags word
+    only says what the lists themselves show (cut at gather_cap / at det_cap)."""
     import torch
     import torch.distributed as dist
-    wire = pack_lists(dets, counts, gather_cap)
+    wire = pack_lists(dets, counts, gather_cap, raw_counts=raw_counts, plan_flags=plan_flags)
+    if rank_failed:
+        wire = torch.zeros_like(wire)
+        wire[:, 1] = WIRE_RANK_FAILED
     if wire.shape[0] < frames_per_rank:
         pad = torch.zeros((frames_per_rank - wire.shape[0], wire.shape[1]), dtype=wire.dtype, device=wire.device)
         pad[:, 1] = WIRE_PADDING

@@ -85,6 +85,50 @@ def _worker_cabi(rank, world, port, nframes, cap, gcap, ret):
         dist.destroy_process_group()
 
 
+def _worker_flags(rank, world, port, nframes, cap, gcap, ret):
+    """allgather_lists with the scan's flags handed through: the torch.distributed path writes the flags word the C ABI's
+    device-side packer writes (raw lists cut at det_cap, the producing rank's queue / would-panic flags, a rank whose scan failed)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = distributed.shard_bounds(nframes, rank, world)
+        dets, counts = _fake_lists(lo, hi, cap)
+        idx, per = distributed.gathered_frame_index(nframes, world)
+        raw = counts.clone()
+        if rank == 0:
+            raw[1] = cap + 5  # the RAW list of rank 0's second frame was cut at det_cap
+        wire = distributed.allgather_lists(dets, counts, gcap, per, raw_counts=raw, plan_flags=(1, 0, 0) if rank == 1 else (0, 0, 0))
+        fl = distributed.row_flags(wire)
+        ok = True
+        for row, f in enumerate(idx.tolist()):
+            if f < 0:
+                ok &= int(fl[row]) == distributed.WIRE_PADDING
+                continue
+            k = (f * 7) % (cap + 3)
+            want = (distributed.WIRE_TRUNCATED_GATHER if k > gcap else 0) | (distributed.WIRE_TRUNCATED_DETCAP if (k > cap or f == 1) else 0)
+            if row >= per:
+                want |= distributed.WIRE_QUEUE_OVERFLOW  # every row of rank 1 says its queue overflowed
+            ok &= int(fl[row]) == want
+        # a rank whose scan was refused: padding rows that say so
+        wire2 = distributed.allgather_lists(dets, counts, gcap, per, rank_failed=(rank == 1))
+        fl2, cnt2 = distributed.row_flags(wire2), wire2[:, 0].numpy()
+        nloc1 = distributed.shard_bounds(nframes, 1, world)
+        n1 = nloc1[1] - nloc1[0]
+        ok &= bool((fl2[per:per + n1] == distributed.WIRE_RANK_FAILED).all()) and bool((cnt2[per:] == 0).all())
+        ok &= bool((fl2[:per] & distributed.WIRE_RANK_FAILED == 0).all())
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgather_lists_carries_the_scan_flags_gloo_world2():
+    world, nframes, cap, gcap = 2, 7, 12, 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_flags, args=(world, _free_port(), nframes, cap, gcap, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -1013,6 +1013,69 @@ def test_one_launch_plans_hand_off_under_uneven_load(pg, orc, nframes, angle, ki
     big.status()
 
 
+def test_one_launch_plans_next_to_another_process(pg, orc):
+    """The hand-offs of k_scan_one with ANOTHER PROCESS keeping the device busy (its 64-frame batch plan in a loop): the launch's
+    workgroups get the chip in pieces and late.  Every one of 300 launches must return the first one's lists -- the oracle's --
+    and none may give up a hand-off (PIGO_ERR_TIMEOUT; the wait is bounded by wall-clock time, PIGO_ONE_TIMEOUT_MS, since
+    round 6 -- 2^17 polls before, which a descheduled launch can exceed while perfectly healthy).  core/pigo.go:212-258."""
+    import subprocess
+    import sys
+    import time
+    import torch
+    from pigo_amd import batch
+    rows, cols = 720, 1280
+    hog = subprocess.Popen([sys.executable, "-c", (
+        "import os, sys, time\n"
+        "sys.path.insert(0, os.getcwd())\n"
+        "import torch\n"
+        "from pigo_amd import batch, core, synth\n"
+        "pg = core.NewPigo(0).Unpack(synth.facefinder_bytes())\n"
+        "plan = batch.ScanPlan(pg, 720, 1280, max_frames=64, det_cap=1024)\n"
+        "fr = torch.from_numpy(synth.make_frames('faces', 64, 720, 1280, seed=5)).cuda()\n"
+        "d, c = plan.alloc_outputs(64)\n"
+        "print('hog ready', flush=True)\n"
+        "t0 = time.time()\n"
+        "n = 0\n"
+        "while time.time() - t0 < float(sys.argv[1]):\n"
+        "    for _ in range(8):\n"
+        "        plan.run(fr, d, c)\n"
+        "    torch.cuda.synchronize()\n"
+        "    n += 8\n"
+        "plan.status()\n"
+        "print('hog steps', n, flush=True)\n"), "12"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        line = hog.stdout.readline()
+        assert "hog ready" in line, line + hog.stdout.read()
+        for nframes, angle in ((1, 0.0), (3, 0.0)):
+            frames = synth.make_frames("faces", nframes, rows, cols, seed=31)
+            plan = batch.ScanPlan(pg, rows, cols, angle=angle, max_frames=nframes, det_cap=2048)
+            assert plan.info().variant == 3
+            dev = torch.from_numpy(frames).cuda()
+            dets, counts = plan.alloc_outputs(nframes)
+            plan.run(dev, dets, counts)
+            torch.cuda.synchronize()
+            plan.status()
+            got = batch.dets_to_numpy(dets, counts)
+            for f in range(nframes):
+                assert_same_dets(got[f], orc.run_cascade(frames[f], rows, cols, cols, 20, 1000, 0.1, 1.1, angle), f"frame {f} next to the other process", Q_TOL_RAW)
+            ref_d, ref_c = dets.clone(), counts.clone()
+            for i in range(150):
+                assert hog.poll() is None, "the other process ended early: " + hog.stdout.read()
+                dets.zero_()
+                plan.run(dev, dets, counts)
+                torch.cuda.current_stream().synchronize()
+                plan.status()  # raises on PIGO_ERR_TIMEOUT / a queue flag
+                assert torch.equal(counts, ref_c) and torch.equal(dets, ref_d), f"launch {i} ({nframes} frames) next to another process differs from the first"
+    finally:
+        try:
+            out, _ = hog.communicate(timeout=60)
+        except subprocess.TimeoutExpired:
+            hog.kill()
+            out = ""
+    assert "hog steps" in out, out
+
+
 def _small_face(f, crop=None):
     """The sample face shrunk by the integer factor f (box average), optionally cropped: faces of scale ~24...40 in frames of a
     few regions."""
