@@ -1045,8 +1045,13 @@ def test_one_launch_plans_next_to_another_process(pg, orc):
         "print('hog steps', n, flush=True)\n"), "12"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     try:
-        line = hog.stdout.readline()
-        assert "hog ready" in line, line + hog.stdout.read()
+        seen = ""
+        for _ in range(50):  # (the runtime may print a line or two of its own first)
+            line = hog.stdout.readline()
+            seen += line
+            if "hog ready" in line or not line:
+                break
+        assert "hog ready" in seen, seen + hog.stdout.read()
         for nframes, angle in ((1, 0.0), (3, 0.0)):
             frames = synth.make_frames("faces", nframes, rows, cols, seed=31)
             plan = batch.ScanPlan(pg, rows, cols, angle=angle, max_frames=nframes, det_cap=2048)
