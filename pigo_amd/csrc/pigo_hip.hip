@@ -379,10 +379,21 @@ extern "C" pigo_status pigo_cascade_create(const uint8_t *packet, size_t len, in
         // the call's latency is the number of dependent passes, not the traffic (one 1080p frame: 0.203 ms vs 0.223 ms).
         // Third table: k_big_pool's steps (lane = window, up to kBigSeg trees of a window in flight): a step that starts at tree t
         // ends right behind the next tree a window can die at, so no tree is walked that the reference would not have reached.
+        // Round 6: from tree PIGO_DEEP_LONG (default 88) on a pass runs to the LAST such tree within its 64 lanes instead of the
+        // first: what is still alive there is a face with few exceptions (facefinder rejects 99.95 % of all windows by tree 100) and
+        // will be walked to the end, so the number of dependent passes is what it costs -- 11 instead of 15 for a window that passes
+        // all 468 trees (the 4K stress config keeps 13 k of them per frame: its deep tail IS its step).
+        const int long_from = std::max(0, env_int("PIGO_DEEP_LONG", 88));
         std::vector<int16_t> pe((size_t)nt * 3);
         for (int t = 0; t < nt; ++t) {
             int e = std::min(t + 15, nt - 1);
             while (e < nt - 1 && !(c->thr[e] > lo)) ++e;
+            if (t >= long_from) {
+                int last = -1;
+                for (int j = std::min(t + 63, nt - 1); j > e && last < 0; --j)
+                    if (c->thr[j] > lo || j == nt - 1) last = j;
+                if (last > e) e = last;
+            }
             pe[(size_t)t] = (int16_t)std::min(e + 1, t + 64);
             pe[(size_t)nt + t] = (int16_t)std::min(nt, t + 64);
             int e2 = t;

@@ -79,6 +79,7 @@ def main():
         for k, v in kv.items():
             os.environ[k] = v
         try:
+            pg = core.NewPigo(0).Unpack(synth.facefinder_bytes())  # (a handle per spec: some switches are read when the cascade is unpacked)
             plan = batch.ScanPlan(pg, a.rows, a.cols, MinSize=a.min_size, MaxSize=a.max_size, ShiftFactor=a.shift, ScaleFactor=a.scale,
                                   angle=a.angle, max_frames=n, det_cap=a.det_cap)
         finally:
