@@ -1,20 +1,30 @@
 // lds_valu_mix.hip -- does a wave's LDS gather work OVERLAP with its VALU work on gfx950, or do the two pipes take turns?
 //
-// k_scan_region's time is (LDS-array cycles) + (VALU cycles) within 5 % (profiles/r05_region_model.md), not their maximum.  This
-// microbenchmark isolates the question with the kernel's own inner loop -- reg_walk of pigo_kernels.hip.inc: per tree level and
-// window ONE ds_read_b64 (the packed offset pairs of both children), TWO ds_read_u8 (the pixels, pigo.go:126-135), a compare, two
-// selects and the next node's address, N windows per lane side by side -- over a synthetic region and a synthetic tree, and turns
-// three knobs the kernel cannot turn by itself:
-//   K      extra one-cycle-class VALU instructions (v_xad_u32, on the walk's dependent chain) per window and level on top of the
-//          walk's own ~8: if the pipes overlapped, time would stay flat in K until the VALU became the longer pipe;
-//   PAT    the pixel reads' address pattern: coherent (every lane at the same node: 2.5 LDS cycles per read) or divergent (each
-//          lane at its own node, offsets uniform in +-R: ~6.9 cycles): the same VALU work over a cheap and an expensive LDS side;
-//   MODE   the schedule inside a wave (3: the child's entry loaded AFTER the compare, see there): 0 lock step (all loads of a level, then all arithmetic -- rounds 1-4), 1 two half-batches
-//          half a level apart (round 5's reg_walk), 2 a rotation window by window (retire window n, issue its next level at once:
-//          the wave never has fewer than N-1 windows' loads in flight);
-//   waves  16 / 12 / 8 per CU (4, 3, 2 per SIMD) and N = 8 / 4 windows per lane.
-// Output: cycles per (window-level of one wave) per CU -- wall time x clock / (levels x windows x waves per CU) -- so that the LDS
-// pipe's share (3 instructions) and the VALU's ((8 + K) x 2 cycles / 4 SIMDs) can be read against it directly.
+// Round 5 modelled k_scan_region's time as (LDS-array cycles) + (VALU cycles at 2 per wave64 instruction), within 5 %, and
+// concluded that the two pipes take turns (profiles/r05_region_model.md).  This microbenchmark isolates the question with the
+// kernel's own inner loop -- reg_walk of pigo_kernels.hip.inc: per tree level and window ONE ds_read_b64 (the packed offset pairs
+// of both children), TWO ds_read_u8 (the pixels, pigo.go:126-135), a compare, two selects and the next node's address, N windows
+// per lane side by side -- over a synthetic region and a synthetic tree, and turns knobs the kernel cannot turn by itself:
+//   K      extra VALU instructions (v_xad_u32, on the walk's dependent chain) per window and level on top of the walk's own ~7;
+//   PAT    the pixel reads' address pattern: coherent (every lane reads base + lane * step + the SAME offset whatever node it
+//          stands on: conflict-free) or divergent (each node its own offsets, uniform in +-12 rows / columns; the lanes spread
+//          over the nodes level by level as in a real walk);
+//   MODE   the schedule inside a wave: 0 lock step (all loads of a level, then all arithmetic -- rounds 1-4), 1 two half-batches
+//          half a level apart (round 5's reg_walk), 2 a rotation window by window (retire window n, issue its next level at once),
+//          3 the child's 4-byte entry loaded AFTER the compare (the bit enters the node index through v_addc: 5 instead of 6
+//          VALU instructions per window-level, two LDS round trips instead of one);
+//   waves  16 / 12 / 8 per CU (4, 3, 2 per SIMD) and N = 8 / 4 windows per lane;
+//   and the same arithmetic WITHOUT the loads (register moves in their place): the VALU side alone.
+// Output: cycles per (window-level of one wave) per CU -- wall time x clock / (levels x windows x waves per CU).
+// What it showed (profiles/r06_lds_valu_mix.txt, r06_experiments.md section 1):
+//   * an extra VALU instruction per window-level costs 1.05 cycles per CU = 4.2 cycles per SIMD at every occupancy: a wave64 VALU
+//     instruction of this class takes a SIMD 4 cycles, not the 2 that MI355X_MICROARCH.md quotes for v_fma_f32 (valu_rate.hip has
+//     the table per opcode).  Round 5's "VALU 37 % busy" was therefore ~75 % busy, and its sum model only fitted by coincidence;
+//   * the pipes DO overlap here: with the LDS side at ~11.9 cycles per window-level (divergent) and the VALU side at 11.1 (K = 4)
+//     the mix runs at 12.6 -- max(), not sum(); coherent: LDS ~7.5, VALU 7.2, mix 7.7.  The schedule inside the wave (modes 0-2) is
+//     worth nothing, the dependent entry load (mode 3) loses;
+//   * so what k_scan_region loses against max() is not in the walk's steady state: it is in what surrounds it (decode, compaction,
+//     queue traffic, chunk claims, the stage boundaries' drains) and in the latency-bound small batches of the later stages.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/micro/lds_valu_mix.hip -o scripts/micro/lds_valu_mix && scripts/micro/lds_valu_mix
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -262,7 +272,7 @@ int main(int argc, char **argv)
     r.ghz = prop.clockRate / 1e6;
     printf("device %s, %d CUs, nominal %.0f MHz.  cycles per (window x level) of one wave, per CU; one workgroup per CU\n", prop.name, r.cus, prop.clockRate / 1000.0);
     printf("columns: K = 0 4 8 16 24 extra VALU instructions per window-level (the walk's own: ~8); then the same arithmetic WITHOUT the loads (K = 0 8 24)\n");
-    printf("a window-level is 1 ds_read_b64 + 2 ds_read_u8; VALU pipe alone: (8 + K) x 2 cycles / 4 SIMDs = 4 + K / 2 cycles per window-level\n");
+    printf("a window-level is 1 ds_read_b64 + 2 ds_read_u8 and ~7 VALU instructions; mode 3 has no variant without loads (its last three columns repeat the mix)\n");
     std::vector<uint8_t> pix(kPixBytes);
     std::mt19937 rng(777);
     for (auto &p : pix) p = (uint8_t)(rng() & 0xff);
