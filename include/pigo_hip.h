@@ -89,7 +89,10 @@ pigo_status pigo_run_cascade(pigo_cascade *c, const uint8_t *pixels, size_t npix
 /* ---- (*Pigo).ClusterDetections, core/pigo.go:262-308 ---------------------------------------------
  * Sorts `dets` in place by ascending Q exactly like the reference's sort.Slice (Go's pdqsort,
  * restated host-side), then runs the IoU clustering on the GPU.  `out` needs room for up to n
- * clusters.  No limit on n (lists beyond 2048 entries take the seeds / members / compact kernels). */
+ * clusters.  No limit on n (lists beyond 2048 entries take the seeds / members / compact kernels).
+ * Re-entrant like the reference's (a pure function that goroutines call concurrently on one *Pigo,
+ * examples/web/main.go:141-144): a call owns a slot of the handle -- pinned staging, a stream, device
+ * scratch -- for its duration, the handle's lock covers the slot list only. */
 pigo_status pigo_cluster_detections(pigo_cascade *c, pigo_det *dets, int n, double iou_threshold, pigo_det *out, int cap,
                                     int *n_out);
 /* The sort step alone (host): sort.Slice(dets, func(i, j) bool { return dets[i].Q < dets[j].Q }), pigo.go:264 */
