@@ -692,7 +692,9 @@ def main():
                     "fabric_bytes_per_frame": int(trec.get("fabric_bytes_per_frame", 0)),
                     "ea_read_bytes_per_frame": trec.get("ea_read_bytes_per_frame_64B_requests"),
                     "dram_destined_share_of_read_requests": trec.get("dram_destined_share_of_read_requests"),
-                    "l2_hit_rate": {k.split("<")[0]: v.get("hit_rate") for k, v in (trec.get("l2_per_step") or {}).items()}}
+                    # (per kernel NAME the instantiation with the most requests: k_tail_deep also has a tiny second launch)
+                    "l2_hit_rate": {k.split("<")[0]: v.get("hit_rate") for k, v in
+                                    sorted((trec.get("l2_per_step") or {}).items(), key=lambda kv: kv[1].get("hits", 0) + kv[1].get("misses", 0))}}
             tnote = (f"profiled offline (profiles/{tname}, commit {trec.get('commit')}): L2-miss (fabric-side) bytes of the scan kernels = 2 x FETCH_SIZE + WRITE_SIZE per frame, "
                      "separate rocprofv3 --pmc passes, x frames; FETCH_SIZE x 2 agrees with TCC_MISS_sum x 128 B on these byte gathers; "
                      f"profiled on {trec.get('frames_per_step')} frames per step; the Infinity Cache sits behind the counted interface (no counter of this stack "
@@ -749,10 +751,12 @@ def main():
                 "traffic_note": tnote,
                 "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "compulsory bytes only (each frame read once + 16 B per detection); the scan is not bound by HBM: the region kernel's time is "
-                        "its LDS cycles (68 % of the time; 48 % of them bank conflicts of divergent byte gathers, as the bank model predicts) plus its "
-                        "VALU cycles (37 %) within 5 % -- profiles/r05_region_model.md; the 1 % largest windows -- gathered from global memory by the "
-                        "side chain that runs NEXT to the region workgroups -- by the L1 fill path (a 128-byte line per gathered byte) -- DESIGN.md section 4",
+                "note": "compulsory bytes only (each frame read once + 16 B per detection); the scan is not bound by HBM: the region kernel keeps its "
+                        "LDS pipe ~68 % busy (48 % of those cycles are bank conflicts of divergent byte gathers, as the bank model predicts) and its VALU "
+                        "~75-80 % (a wave64 VALU instruction of the kinds the scan is made of costs a SIMD 4 cycles, not 2: profiles/r06_valu_rate.txt, "
+                        "r06_experiments.md section 1), the stages behind the first tree are chains of dependent LDS round trips; the 1 % largest windows -- "
+                        "gathered from global memory by the side chain that runs NEXT to the region workgroups -- are bound by the L1 fill path (a 128-byte "
+                        "line per gathered byte) -- DESIGN.md section 4",
             },
         }
         out["config3_shard"] = shard_leg
