@@ -661,6 +661,19 @@ def main():
                        "rotated_faces": config_leg(args, pg, dev, "config-4 leg (rotated faces)", 64, 5, 64 if vall else 0, angle=0.8, face_rotation=-79.0)}
         config5_leg = config_leg(args, pg, dev, "config-5 leg (4K)", 8, 3, 8 if vall else 0, rows=2160, cols=3840, min_size=20, max_size=2000, shift=0.05,
                                  scale=1.05, det_cap=32768)
+        # (8 frames give every XCD ONE frame: the chip is not full.  The same configuration on 64 resident frames -- 531 MB, twice the
+        # Infinity Cache -- is the batch the traffic profile profiles/r06_traffic_4k.json was taken on; every frame verified as well)
+        config5_leg["batch_of_64"] = config_leg(args, pg, dev, "config-5 leg (4K, 64 frames)", 64, 2, 64 if vall else 0, rows=2160, cols=3840, min_size=20,
+                                                max_size=2000, shift=0.05, scale=1.05, det_cap=32768)
+        t4 = os.path.join(ROOT, "profiles", "r06_traffic_4k.json")
+        if os.path.exists(t4):
+            with open(t4) as fh:
+                tr4 = json.load(fh)
+            config5_leg["batch_of_64"]["roofline"]["traffic"] = int(tr4["fabric_bytes_per_frame"]) * 64
+            config5_leg["batch_of_64"]["roofline"]["traffic_source"] = {
+                "file": "profiles/r06_traffic_4k.json", "commit": tr4.get("commit"), "frames_per_step_profiled": tr4.get("frames_per_step"),
+                "fabric_bytes_per_frame": int(tr4["fabric_bytes_per_frame"]), "ea_read_bytes_per_frame": tr4.get("ea_read_bytes_per_frame_64B_requests"),
+                "note": "fabric-side (L2-miss) bytes: 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes (scripts/gpu_r6_traffic_4k.sh); an upper bound of the HBM bytes"}
         ref_leg = reference_benchmark_leg(args, pg)
 
     if rank == 0:
