@@ -1052,7 +1052,7 @@ bool build_region_groups(pigo_plan &p)
                 r.quad = want;
         r.compress = compress ? 1 : 0;
         r.cut = env_int("PIGO_REG_CUT", 0);  // (read by the debug build only)
-        r.one_local = one_mode ? std::max(0, std::min(8, env_int(g == 0 ? "PIGO_ONE_LOCAL0" : "PIGO_ONE_LOCAL1", 1))) : 0;
+        r.one_local = one_mode ? std::max(0, std::min(8, env_int(g == 0 ? "PIGO_ONE_LOCAL0" : "PIGO_ONE_LOCAL1", g == 0 ? 1 : 2))) : 0;
         r.wave_q = wq;
         for (int j = k_lo; j < k; ++j)
             if (p.scales[j].s >= (1 << 14)) REG_BAIL;
@@ -1222,7 +1222,7 @@ void build_one(pigo_plan &p)
     p.one_lds = lds;
     o.nt = std::max(1, std::min(4, env_int("PIGO_ONE_NT", 1)));
     o.nt_late = std::max(1, std::min(4, env_int("PIGO_ONE_NT_LATE", 4)));
-    o.late_items = std::max(0, env_int("PIGO_ONE_LATE_ITEMS", 8));
+    o.late_items = std::max(0, env_int("PIGO_ONE_LATE_ITEMS", 4));  // (round 6: 4 and two local passes in the mid group -- 0.1013-0.1017 against 0.1030-0.1041 ms on a 1080p frame with faces, neutral elsewhere)
     o.plain_zero = env_int("PIGO_ONE_PLAINZERO", 0);
     // (a user switch, always honoured: how long a consumer of the one-launch scan waits for a claimed slot before the run is given up)
     o.wait_ticks = (long long)std::max(1, std::min(600000, env_int("PIGO_ONE_TIMEOUT_MS", 2000))) * 100000LL;
