@@ -663,7 +663,7 @@ def main():
                                  scale=1.05, det_cap=32768)
         # (8 frames give every XCD ONE frame: the chip is not full.  The same configuration on 64 resident frames -- 531 MB, twice the
         # Infinity Cache -- is the batch the traffic profile profiles/r06_traffic_4k.json was taken on; every frame verified as well)
-        config5_leg["batch_of_64"] = config_leg(args, pg, dev, "config-5 leg (4K, 64 frames)", 64, 2, 64 if vall else 0, rows=2160, cols=3840, min_size=20,
+        config5_leg["batch_of_64"] = config_leg(args, pg, dev, "config-5 leg (4K, 64 frames)", 64, 4, 64 if vall else 0, rows=2160, cols=3840, min_size=20,
                                                 max_size=2000, shift=0.05, scale=1.05, det_cap=32768)
         t4 = os.path.join(ROOT, "profiles", "r06_traffic_4k.json")
         if os.path.exists(t4):
